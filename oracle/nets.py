@@ -1,0 +1,353 @@
+"""Oracle networks: torch-CPU restatement of smp 0.3.3 Unet / UnetPlusPlus /
+Linknet over torchvision ResNet encoders (TEST INFRASTRUCTURE ONLY).
+
+The module tree reproduces the upstream attribute names so that
+``state_dict()`` keys equal the ones a reference checkpoint holds
+(``model.encoder.layer1.0.conv1.weight`` ...).
+Call site restated: reference ``src/models/smp/model.py:38-44``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# smp.encoders.get_preprocessing_params(name) for the torchvision ResNets
+# (reference src/models/smp/model.py:49).
+_IMAGENET = {
+    'input_space': 'RGB',
+    'input_range': [0, 1],
+    'mean': [0.485, 0.456, 0.406],
+    'std': [0.229, 0.224, 0.225],
+}
+
+ENCODER_CHANNELS = {
+    'resnet18': (3, 64, 64, 128, 256, 512),
+    'resnet34': (3, 64, 64, 128, 256, 512),
+    'resnet50': (3, 64, 256, 512, 1024, 2048),
+    'resnet101': (3, 64, 256, 512, 1024, 2048),
+}
+_RESNET_CFG = {
+    'resnet18': ('basic', (2, 2, 2, 2)),
+    'resnet34': ('basic', (3, 4, 6, 3)),
+    'resnet50': ('bottleneck', (3, 4, 6, 3)),
+    'resnet101': ('bottleneck', (3, 4, 23, 3)),
+}
+
+
+def get_preprocessing_params(encoder_name, pretrained='imagenet'):
+    if encoder_name not in ENCODER_CHANNELS:
+        raise KeyError(f'Wrong encoder name `{encoder_name}`')
+    return dict(_IMAGENET)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)  # v1.5: stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNetEncoder(nn.Module):
+    """torchvision ResNet minus avgpool/fc, returning the 6 smp features."""
+
+    def __init__(self, name, in_channels=3):
+        super().__init__()
+        kind, layers = _RESNET_CFG[name]
+        block = BasicBlock if kind == 'basic' else Bottleneck
+        self.out_channels = ENCODER_CHANNELS[name]
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0], 1)
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        for m in self.modules():  # torchvision init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        f0 = x
+        f1 = self.relu(self.bn1(self.conv1(x)))
+        f2 = self.layer1(self.maxpool(f1))
+        f3 = self.layer2(f2)
+        f4 = self.layer3(f3)
+        f5 = self.layer4(f4)
+        return [f0, f1, f2, f3, f4, f5]
+
+
+class Conv2dReLU(nn.Sequential):
+    def __init__(self, cin, cout, kernel_size, padding=0):
+        super().__init__(
+            nn.Conv2d(cin, cout, kernel_size, padding=padding, bias=False),
+            nn.BatchNorm2d(cout),
+            nn.ReLU(inplace=True),
+        )
+
+
+class UnetDecoderBlock(nn.Module):
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.conv1 = Conv2dReLU(cin + cskip, cout, 3, 1)
+        self.attention1 = nn.Identity()
+        self.conv2 = Conv2dReLU(cout, cout, 3, 1)
+        self.attention2 = nn.Identity()
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+        if skip is not None:
+            x = torch.cat([x, skip], dim=1)
+        return self.conv2(self.conv1(x))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=(256, 128, 64, 32, 16)):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        ins = [enc[0]] + list(decoder_channels[:-1])
+        skips = enc[1:] + [0]
+        self.center = nn.Identity()
+        self.blocks = nn.ModuleList(
+            [UnetDecoderBlock(i, s, o) for i, s, o in zip(ins, skips, decoder_channels)])
+
+    def forward(self, *features):
+        features = features[1:][::-1]
+        x = self.center(features[0])
+        skips = features[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class UnetPlusPlusDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=(256, 128, 64, 32, 16)):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        self.in_channels = [enc[0]] + list(decoder_channels[:-1])
+        self.skip_channels = enc[1:] + [0]
+        self.out_channels = list(decoder_channels)
+        blocks = {}
+        for layer_idx in range(len(self.in_channels) - 1):
+            for depth_idx in range(layer_idx + 1):
+                if depth_idx == 0:
+                    in_ch = self.in_channels[layer_idx]
+                    skip_ch = self.skip_channels[layer_idx] * (layer_idx + 1)
+                    out_ch = self.out_channels[layer_idx]
+                else:
+                    out_ch = self.skip_channels[layer_idx]
+                    skip_ch = self.skip_channels[layer_idx] * (layer_idx + 1 - depth_idx)
+                    in_ch = self.skip_channels[layer_idx - 1]
+                blocks[f'x_{depth_idx}_{layer_idx}'] = UnetDecoderBlock(in_ch, skip_ch, out_ch)
+        blocks[f'x_0_{len(self.in_channels) - 1}'] = UnetDecoderBlock(
+            self.in_channels[-1], 0, self.out_channels[-1])
+        self.blocks = nn.ModuleDict(blocks)
+        self.depth = len(self.in_channels) - 1
+
+    def forward(self, *features):
+        features = features[1:][::-1]
+        dense = {}
+        for layer_idx in range(len(self.in_channels) - 1):
+            for depth_idx in range(self.depth - layer_idx):
+                if layer_idx == 0:
+                    dense[f'x_{depth_idx}_{depth_idx}'] = self.blocks[f'x_{depth_idx}_{depth_idx}'](
+                        features[depth_idx], features[depth_idx + 1])
+                else:
+                    li = depth_idx + layer_idx
+                    cat = [dense[f'x_{idx}_{li}'] for idx in range(depth_idx + 1, li + 1)]
+                    cat = torch.cat(cat + [features[li + 1]], dim=1)
+                    dense[f'x_{depth_idx}_{li}'] = self.blocks[f'x_{depth_idx}_{li}'](
+                        dense[f'x_{depth_idx}_{li - 1}'], cat)
+        dense[f'x_0_{self.depth}'] = self.blocks[f'x_0_{self.depth}'](dense[f'x_0_{self.depth - 1}'])
+        return dense[f'x_0_{self.depth}']
+
+
+class TransposeX2(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(
+            nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1),
+            nn.BatchNorm2d(cout),
+            nn.ReLU(inplace=True),
+        )
+
+
+class LinknetDecoderBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.block = nn.Sequential(
+            Conv2dReLU(cin, cin // 4, 1),
+            TransposeX2(cin // 4, cin // 4),
+            Conv2dReLU(cin // 4, cout, 1),
+        )
+
+    def forward(self, x, skip=None):
+        x = self.block(x)
+        if skip is not None:
+            x = x + skip
+        return x
+
+
+class LinknetDecoder(nn.Module):
+    def __init__(self, encoder_channels, prefinal_channels=32, n_blocks=5):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        ch = enc + [prefinal_channels]
+        self.blocks = nn.ModuleList([LinknetDecoderBlock(ch[i], ch[i + 1]) for i in range(n_blocks)])
+
+    def forward(self, *features):
+        features = features[1:][::-1]
+        x = features[0]
+        skips = features[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, cin, cout, kernel_size):
+        super().__init__(
+            nn.Conv2d(cin, cout, kernel_size, padding=kernel_size // 2),
+            nn.Identity(),
+            nn.Identity(),
+        )
+
+
+def _init_decoder(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_uniform_(m.weight, mode='fan_in', nonlinearity='relu')
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+def _init_head(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class SegmentationModel(nn.Module):
+    def __init__(self, arch, encoder_name, in_channels, classes):
+        super().__init__()
+        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        ch = self.encoder.out_channels
+        if arch == 'unet':
+            self.decoder = UnetDecoder(ch)
+            self.segmentation_head = SegmentationHead(16, classes, 3)
+        elif arch == 'unetplusplus':
+            self.decoder = UnetPlusPlusDecoder(ch)
+            self.segmentation_head = SegmentationHead(16, classes, 3)
+        elif arch == 'linknet':
+            self.decoder = LinknetDecoder(ch)
+            self.segmentation_head = SegmentationHead(32, classes, 1)
+        else:
+            raise KeyError(arch)
+        _init_decoder(self.decoder)
+        _init_head(self.segmentation_head)
+
+    def forward(self, x):
+        h, w = x.shape[-2:]
+        if h % 32 != 0 or w % 32 != 0:
+            raise RuntimeError(
+                f'Wrong input shape height={h}, width={w}. Expected image height and width '
+                f'divisible by 32.')
+        return self.segmentation_head(self.decoder(*self.encoder(x)))
+
+
+_ARCHS = ('unet', 'unetplusplus', 'linknet')
+
+
+def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):
+    """smp.create_model restated (reference src/models/smp/model.py:38-44).
+
+    ``encoder_weights`` is accepted and ignored: no pretrained blobs exist
+    offline, weights come from the seeded torch RNG.
+    """
+    a = arch.lower()
+    if a not in _ARCHS:
+        raise KeyError(f'Wrong architecture type `{arch}`. Available options are: {list(_ARCHS)}')
+    if encoder_name not in ENCODER_CHANNELS:
+        raise KeyError(f'Wrong encoder name `{encoder_name}`, supported: {list(ENCODER_CHANNELS)}')
+    return SegmentationModel(a, encoder_name, in_channels, classes)
+
+
+def conv_param_count(model):
+    return sum(p.numel() for n, p in model.named_parameters() if p.dim() == 4)
+
+
+def randomize_bn(model, seed=0):
+    """Give BN affine params / running stats non-trivial values so parity tests
+    exercise gamma/beta/running buffers (fresh init is 1/0/0/1)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(1.0 + 0.2 * torch.rand(m.running_var.shape, generator=g))
+    return model
+
+
+_ = math
