@@ -1,0 +1,130 @@
+/* octseg.h -- C ABI of liboctseg_hip.so, the MI355X (gfx950) engine behind the OCT segmentation
+ * hot path: encoder-decoder forward + backward + Dice loss + optimizer step.
+ *
+ * The reference (ViacheslavDanilov/oct_segmentation) has no FFI: its seam is Python.  Each entry
+ * point below names the reference call it sits under (paths relative to the reference repo):
+ *
+ *   octseg_plan_create / _destroy      smp.create_model(arch, encoder_name, in_channels, classes)
+ *                                      src/models/smp/model.py:38-44
+ *   octseg_plan_param_info / bn_info   the nn.Module parameter / buffer tree behind state_dict()
+ *                                      (load_from_checkpoint, src/predict.py:39-48)
+ *   octseg_net_forward                 OCTSegmentationModel.forward (normalize=1, model.py:65-71) and
+ *                                      .predict's bare self.model(x) (normalize=0, model.py:192)
+ *   octseg_dice_forward                smp.losses.DiceLoss(MULTILABEL_MODE, from_logits=True)
+ *                                      (model.py:55,81,115) + smp.metrics.get_stats (utils.py:19-23)
+ *   octseg_net_backward                loss.backward() that Lightning runs after training_step
+ *                                      (model.py:73-95, train.py:130-133)
+ *   octseg_optim_step                  configure_optimizers -> SGD|RMSprop|RAdam|Adam.step()
+ *                                      (model.py:150-181)
+ *   octseg_conv2d_* / _convT_*         torch conv2d / conv_transpose2d primitives, exported so the
+ *                                      parity tests can pin every kernel against torch CPU in isolation
+ *
+ * Conventions: every function returns 0 on success or a negative octseg_status; the message of the
+ * last failure on the calling thread is octseg_last_error().  Nothing throws across the ABI.  The
+ * caller owns every buffer (device pointers, plain sizes); the library only enqueues kernels on the
+ * caller's hipStream_t (passed as void*) and never synchronises or allocates in hot calls.  Plans
+ * are thread-compatible (no concurrent calls on one plan).
+ */
+#ifndef OCTSEG_H
+#define OCTSEG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  OCTSEG_OK = 0,
+  OCTSEG_BAD_SHAPE = -1,        /* e.g. H or W not divisible by 32 (smp check_input_shape) */
+  OCTSEG_BAD_DTYPE = -2,
+  OCTSEG_UNSUPPORTED_ARCH = -3, /* unknown arch / encoder name */
+  OCTSEG_HIP_ERROR = -4,
+  OCTSEG_BAD_ARG = -5
+} octseg_status;
+
+typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1 } octseg_dtype;
+
+typedef struct {
+  const char* arch;     /* "unet" | "unetplusplus" | "linknet" (case-insensitive) */
+  const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" */
+  int classes;          /* output channels */
+  int batch, height, width;
+  int dtype;            /* octseg_dtype: storage/MFMA input type of activations (accumulate is f32) */
+} octseg_net_desc;
+
+typedef struct octseg_plan octseg_plan;
+
+/* kinds of parameter layout inside the flat fp32 parameter arena */
+enum {
+  OCTSEG_P_CONV = 0,   /* [R][S][O][I]  <- torch Conv2d weight [O][I][R][S]           */
+  OCTSEG_P_CONVT = 1,  /* [R][S][O][I]  <- torch ConvTranspose2d weight [I][O][R][S]  */
+  OCTSEG_P_STEM = 2,   /* [O][KP], k=(r*7+s)*3+ci zero padded to KP <- [O][3][7][7]   */
+  OCTSEG_P_VEC = 3     /* bias / BN weight / BN bias, [O]                              */
+};
+typedef struct {
+  char name[128];      /* state_dict key relative to the smp model, e.g. "encoder.layer1.0.conv1.weight" */
+  int kind;
+  int R, S, O, I, KP;
+  size_t offset;       /* element offset into the parameter (and gradient) arena */
+  size_t numel;
+} octseg_param_info;
+typedef struct {
+  char name[128];      /* module path, e.g. "encoder.bn1"; buffers are <name>.running_mean / running_var */
+  int C;
+  size_t mean_offset, var_offset; /* element offsets into the buffer arena */
+} octseg_bn_info;
+
+int octseg_version(void);
+const char* octseg_last_error(void);
+
+int octseg_plan_create(const octseg_net_desc* desc, octseg_plan** out);
+int octseg_plan_destroy(octseg_plan* plan);
+size_t octseg_plan_workspace_bytes(const octseg_plan* plan);
+size_t octseg_plan_param_numel(const octseg_plan* plan);   /* fp32 elements of the param / grad arenas */
+size_t octseg_plan_buffer_numel(const octseg_plan* plan);  /* fp32 elements of the BN buffer arena */
+int octseg_plan_num_params(const octseg_plan* plan);
+int octseg_plan_param_info(const octseg_plan* plan, int index, octseg_param_info* out);
+int octseg_plan_num_bn(const octseg_plan* plan);
+int octseg_plan_bn_info(const octseg_plan* plan, int index, octseg_bn_info* out);
+double octseg_plan_fwd_macs(const octseg_plan* plan);      /* conv multiply-accumulates of one forward */
+
+/* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
+ * train=1: batch statistics, running buffers updated, activations kept for backward. */
+int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,
+                       const float* image, float* logits, int normalize, const float* mean,
+                       const float* stdv, int train, void* stream);
+
+/* loss: device f32 scalar; stats: device int64 [B][classes][4] = tp, fp, fn, tn (nullable). */
+int octseg_dice_forward(octseg_plan* plan, void* workspace, const float* logits, const float* target,
+                        float* loss, long long* stats, void* stream);
+
+/* Must follow octseg_net_forward(train=1) + octseg_dice_forward on the same workspace.
+ * grads (fp32 arena, same layout as params) is overwritten with d(grad_scale * loss)/dparams. */
+int octseg_net_backward(octseg_plan* plan, const float* params, float* grads, void* workspace,
+                        const float* logits, const float* target, float grad_scale, void* stream);
+
+/* kind: 0 SGD, 1 Adam, 2 RMSprop, 3 RAdam (torch defaults for everything not listed).
+ * state_m / state_v: fp32 arenas of numel elements (may be NULL when unused by the kind). */
+int octseg_optim_step(int kind, float* params, const float* grads, float* state_m, float* state_v,
+                      size_t numel, float lr, float weight_decay, int step, float grad_scale,
+                      void* stream);
+
+/* ---- single-op entry points (NHWC device tensors of `dtype`; weights fp32 in arena layout) ---- */
+/* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w[R][S][Cout][Cin]) (+bias);  transposed=1: ConvTranspose2d
+ * 4x4 s2 p1 with w[R][S][Cout][Cin].  scratch: device bytes >= octseg_conv2d_scratch_bytes(). */
+size_t octseg_conv2d_scratch_bytes(int dtype, int N, int H, int W, int Cin, int Cout, int R, int S);
+int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float* bias, void* y, int N,
+                          int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          int transposed, void* scratch, void* stream);
+int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void* dx, int N, int H, int W,
+                                int Cin, int Cout, int R, int S, int stride, int pad, int transposed,
+                                void* scratch, void* stream);
+int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, float* dw, int N, int H,
+                                  int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  int transposed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTSEG_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of ``liboctseg_hip.so`` (C ABI declared in ``include/octseg.h``).
+
+The product path has no CPU fallback: if the library is missing or a call
+fails, a ``RuntimeError`` is raised with ``octseg_last_error()``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liboctseg_hip.so')
+
+F32, BF16 = 0, 1
+P_CONV, P_CONVT, P_STEM, P_VEC = 0, 1, 2, 3
+OPT_KINDS = {'SGD': 0, 'Adam': 1, 'RMSprop': 2, 'RAdam': 3}
+
+
+class NetDesc(C.Structure):
+    _fields_ = [('arch', C.c_char_p), ('encoder', C.c_char_p), ('classes', C.c_int), ('batch', C.c_int),
+                ('height', C.c_int), ('width', C.c_int), ('dtype', C.c_int)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 128), ('kind', C.c_int), ('R', C.c_int), ('S', C.c_int), ('O', C.c_int),
+                ('I', C.c_int), ('KP', C.c_int), ('offset', C.c_size_t), ('numel', C.c_size_t)]
+
+
+class BNInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 128), ('C', C.c_int), ('mean_offset', C.c_size_t), ('var_offset', C.c_size_t)]
+
+
+# every exported symbol with (restype, argtypes); tests check the library exports all of them
+_P = C.c_void_p
+SYMBOLS = {
+    'octseg_version': (C.c_int, []),
+    'octseg_last_error': (C.c_char_p, []),
+    'octseg_plan_create': (C.c_int, [C.POINTER(NetDesc), C.POINTER(_P)]),
+    'octseg_plan_destroy': (C.c_int, [_P]),
+    'octseg_plan_workspace_bytes': (C.c_size_t, [_P]),
+    'octseg_plan_param_numel': (C.c_size_t, [_P]),
+    'octseg_plan_buffer_numel': (C.c_size_t, [_P]),
+    'octseg_plan_num_params': (C.c_int, [_P]),
+    'octseg_plan_param_info': (C.c_int, [_P, C.c_int, C.POINTER(ParamInfo)]),
+    'octseg_plan_num_bn': (C.c_int, [_P]),
+    'octseg_plan_bn_info': (C.c_int, [_P, C.c_int, C.POINTER(BNInfo)]),
+    'octseg_plan_fwd_macs': (C.c_double, [_P]),
+    'octseg_net_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.c_int, _P]),
+    'octseg_dice_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    'octseg_net_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P]),
+    'octseg_optim_step': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
+    'octseg_conv2d_scratch_bytes': (C.c_size_t, [C.c_int] * 8),
+    'octseg_conv2d_forward': (C.c_int, [C.c_int, _P, _P, _P, _P] + [C.c_int] * 10 + [_P, _P]),
+    'octseg_conv2d_backward_data': (C.c_int, [C.c_int, _P, _P, _P] + [C.c_int] * 10 + [_P, _P]),
+    'octseg_conv2d_backward_weight': (C.c_int, [C.c_int, _P, _P, _P] + [C.c_int] * 10 + [_P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C oct_segmentation_amd/csrc`). There is no CPU fallback.')
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f'octseg error {rc}: {lib().octseg_last_error().decode()}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

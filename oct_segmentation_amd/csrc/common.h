@@ -1,0 +1,81 @@
+// Shared host/device declarations for the octseg gfx950 engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace octseg {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM (same layout as torch.bfloat16)
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+constexpr int MAX_SRC = 5;    // U-Net++ dense concat: up + 3 dense + encoder feature
+constexpr int MAX_TAPS = 49;  // 7x7 (only used by the unit-test entry points)
+
+// One source of a virtual (concatenated / upsampled / lazily normalised) conv input.
+// The consumer applies  relu?(x * scale[c] + shift[c])  on load (scale == nullptr: identity).
+struct SrcDesc {
+  const void* ptr;     // NHWC, element type T
+  const float* scale;  // per source-channel, or nullptr
+  const float* shift;
+  int C;               // channels of this source (== its channel stride)
+  int c0;              // first channel inside the concatenation
+  int H, W;            // stored spatial size
+  int up;              // 1: nearest x2 upsample on read (coord >> 1)
+  int relu;            // apply relu after the affine
+};
+
+// Destination slice for a conv output (forward: one; dgrad: one per forward source).
+struct DstDesc {
+  void* ptr;  // NHWC T, or NCHW f32 in head mode
+  int C;      // channel stride of the destination tensor
+  int c0;     // first output channel mapped to this destination
+  int cn;     // number of channels
+  int H, W;   // full spatial size of the destination tensor
+};
+
+enum OutMode { OUT_STORE = 0, OUT_ACCUM = 1, OUT_HEAD_NCHW = 2 };
+
+struct ConvArgs {
+  SrcDesc src[MAX_SRC];
+  int nsrc;
+  int Cin;         // total concatenated input channels
+  int N, IH, IW;   // virtual input extent (after up)
+  int OH, OW;      // output grid extent (tile iteration space)
+  int ntaps;
+  signed char tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];  // input offset of each tap (pad folded in)
+  unsigned char tap_w[MAX_TAPS];                   // weight slab index of each tap
+  int min_dy, min_dx, span_y, span_x;              // bounding box of the tap offsets
+  int istride;     // input coord = grid * istride + tap offset
+  const void* W;   // [wtaps][Cout][Cin] T  (Cin contiguous)
+  int Cout;
+  DstDesc dst[MAX_SRC];
+  int ndst;
+  int ostride, ooy, oox;  // output pixel = grid * ostride + (ooy, oox)
+  int out_mode;
+  const float* bias;      // per-Cout, nullable
+  float* stat_slab;       // nullable: [slab rows][Cout][2] partial (sum, sumsq) per M tile
+  int slab_row0;
+};
+
+struct WgradArgs {
+  SrcDesc src[MAX_SRC];
+  int nsrc;
+  int Cin;
+  int N, IH, IW;
+  int OH, OW;       // grid extent of dy that is iterated
+  int ntaps;
+  signed char tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
+  unsigned char tap_w[MAX_TAPS];
+  int min_dy, min_dx, span_y, span_x;
+  int istride;
+  const void* dy;   // NHWC T, [N][DH][DW][dyC]
+  int dyC, DH, DW;  // channel stride and full extent of dy
+  int dstride, doy, dox;  // dy pixel = grid * dstride + (doy, dox)
+  int Cout;         // real number of output channels (rows of dW)
+  float* dW;        // [wtaps][Cout][Cin] fp32, accumulated with atomics
+  int ksplit;       // number of pixel-tile groups (grid.z)
+};
+
+}  // namespace octseg

@@ -1,0 +1,138 @@
+// conv_common.h -- device helpers shared by the conv and wgrad MFMA kernels.
+#pragma once
+#include "common.h"
+
+namespace octseg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int TW = 16;                // output-grid tile width (pixels)
+constexpr int NTHR = 256;
+
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+  static constexpr int VEC = 4;  // channels per 16-byte vector
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+  // relu?(x*scale+shift) on a 4-channel vector
+  static __device__ __forceinline__ uint4 affine(uint4 v, const float* sc, const float* sh, int relu) {
+    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[i] = fmaf(x[i], sc[i], sh[i]);
+      if (relu) x[i] = fmaxf(x[i], 0.f);
+    }
+    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+  }
+  static __device__ __forceinline__ float load(const void* p, size_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+};
+static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+template <> struct Tr<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint4 affine(uint4 v, const float* sc, const float* sh, int relu) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+      lo = fmaf(lo, sc[2 * i], sh[2 * i]);
+      hi = fmaf(hi, sc[2 * i + 1], sh[2 * i + 1]);
+      if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+      w[i] = pack_bf16(lo, hi);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ float load(const void* p, size_t i) {
+    return __uint_as_float((unsigned)((const bf16_t*)p)[i] << 16);
+  }
+  static __device__ __forceinline__ void store(void* p, size_t i, float v) {
+    __bf16 b = (__bf16)v;
+    ((bf16_t*)p)[i] = __builtin_bit_cast(unsigned short, b);
+  }
+};
+
+// Per-thread view of the source its channel vector falls into (resolved once per chunk).
+struct SrcSel {
+  const char* ptr; const float* scale; const float* shift;
+  int C, cl, H, W, up, relu;
+};
+static __device__ __forceinline__ SrcSel select_src(const SrcDesc* src, int nsrc, int c) {
+  SrcSel s;
+  s.ptr = (const char*)src[0].ptr; s.scale = src[0].scale; s.shift = src[0].shift;
+  s.C = src[0].C; s.cl = c - src[0].c0; s.H = src[0].H; s.W = src[0].W; s.up = src[0].up; s.relu = src[0].relu;
+#pragma unroll
+  for (int i = 1; i < MAX_SRC; ++i) {
+    if (i < nsrc && c >= src[i].c0) {
+      s.ptr = (const char*)src[i].ptr; s.scale = src[i].scale; s.shift = src[i].shift;
+      s.C = src[i].C; s.cl = c - src[i].c0; s.H = src[i].H; s.W = src[i].W; s.up = src[i].up; s.relu = src[i].relu;
+    }
+  }
+  return s;
+}
+
+// Stage the input window of one channel chunk into LDS (gather + lazy BN/ReLU).
+// Window pixel hp=(hy,hx) <-> virtual input (gy0 + hy*smul, gx0 + hx*smul).
+template <typename T, int RB>
+static __device__ __forceinline__ void stage_window(char* lds, const SrcDesc* src, int nsrc, int Cin,
+                                                    int chunk, int n, int gy0, int gx0, int smul, int RW,
+                                                    int npix, float inv_rw, int IH, int IW, int tid) {
+  constexpr int VEC = Tr<T>::VEC;
+  constexpr int KC = RB / (int)sizeof(T);   // channels per LDS row
+  constexpr int VPR = RB / 16;              // 16-byte vectors per LDS row
+  constexpr int PSTEP = NTHR / VPR;         // window pixels covered per pass
+  constexpr int PITCH = RB + 16;            // padded row pitch (bank spread for wide LDS reads)
+  const int cv = tid % VPR;
+  const int c = chunk * KC + cv * VEC;
+  const bool cvalid = c < Cin;
+  SrcSel s = select_src(src, nsrc, cvalid ? c : 0);
+  float sc[VEC], sh[VEC];
+  const bool has_aff = cvalid && s.scale != nullptr;
+  if (has_aff) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = s.scale[s.cl + i]; sh[i] = s.shift[s.cl + i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+  }
+  constexpr int U = 4;
+  for (int base = tid / VPR; base < npix; base += PSTEP * U) {
+    uint4 v[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int hp = base + PSTEP * u;
+      const int hy = (int)(((float)hp + 0.5f) * inv_rw);
+      const int hx = hp - hy * RW;
+      const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
+      ok[u] = cvalid && hp < npix && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (ok[u]) {
+        const size_t e = (((size_t)n * s.H + (iy >> s.up)) * s.W + (ix >> s.up)) * s.C + s.cl;
+        v[u] = *(const uint4*)(s.ptr + e * sizeof(T));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int hp = base + PSTEP * u;
+      if (hp < npix) {
+        uint4 w = v[u];
+        if (ok[u] && has_aff) w = Tr<T>::affine(w, sc, sh, s.relu);
+        *(uint4*)(lds + hp * PITCH + cv * 16) = w;
+      }
+    }
+  }
+}
+
+
+}  // namespace octseg

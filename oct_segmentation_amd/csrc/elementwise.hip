@@ -1,0 +1,691 @@
+// elementwise.hip -- the HBM-bound kernels of the hot path (gfx950): BatchNorm finalize /
+// apply / backward, residual + skip adds, maxpool, stem im2col, Dice loss, weight packing and
+// the fused optimizers.  Every tensor is NHWC with 16-byte vector accesses (8 x bf16 or 4 x f32
+// per lane); per-channel reductions keep a fixed channel vector per thread so the partial sums
+// stay in registers, then combine through LDS and a deterministic slab (no float atomics on the
+// BN path).
+#include "common.h"
+#include "kernels.h"
+
+namespace octseg {
+
+template <typename T> struct EV;  // 16-byte element vector helpers
+template <> struct EV<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* x) {
+    x[0] = __uint_as_float(v.x); x[1] = __uint_as_float(v.y); x[2] = __uint_as_float(v.z); x[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* x) {
+    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+  }
+};
+static __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+template <> struct EV<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* x) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = __uint_as_float(w[i] << 16); x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ uint4 pack(const float* x) {
+    return make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
+  }
+};
+template <typename T> static __device__ __forceinline__ uint4 ldv(const void* p, size_t vec_idx) {
+  return ((const uint4*)p)[vec_idx];
+}
+template <typename T> static __device__ __forceinline__ void stv(void* p, size_t vec_idx, const uint4& v) {
+  ((uint4*)p)[vec_idx] = v;
+}
+
+static inline int grid_for(size_t n, int block, int cap = 8192) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ BatchNorm finalize
+// one block per 32 channels, 32 row lanes; double accumulation -> deterministic.
+__global__ __launch_bounds__(1024) void bn_finalize_train_kernel(
+    const float* __restrict__ slab, int rows, int C, double count, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+    float* mean_out, float* rstd_out) {
+  __shared__ double red[32][33][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 32) {
+      const float2 v = *(const float2*)(slab + ((size_t)r * C + c) * 2);
+      s1 += (double)v.x; s2 += (double)v.y;
+    }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int r = 1; r < 32; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double count, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float* scale, float* shift, float* mean,
+                                    float* rstd, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, slab, rows, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+  return hipGetLastError();
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                        const float* rv, float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BN apply (+residual, +relu, +skip)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
+  constexpr int VEC = EV<T>::VEC;
+  const size_t nvec = a.npix * (size_t)(a.C / VEC);
+  const int vpc = a.C / VEC;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % vpc) * VEC;
+    float x[VEC];
+    EV<T>::unpack(ldv<T>(a.y, v), x);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] = fmaf(x[i], a.scale[c + i], a.shift[c + i]);
+    if (a.res) {
+      float rr[VEC];
+      EV<T>::unpack(ldv<T>(a.res, v), rr);
+      if (a.rscale) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rr[i] = fmaf(rr[i], a.rscale[c + i], a.rshift[c + i]);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) x[i] += rr[i];
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) x[i] = fmaxf(x[i], 0.f);
+    }
+    if (a.post) {
+      float pp[VEC];
+      EV<T>::unpack(ldv<T>(a.post, v), pp);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) x[i] += pp[i];
+    }
+    stv<T>(a.out, v, EV<T>::pack(x));
+  }
+}
+hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
+  const size_t nvec = a.npix * (size_t)(a.C / (dtype == DT_F32 ? 4 : 8));
+  const int g = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BN backward
+// dz = g * mask;  slab[row][c] = (sum dz, sum dz * xhat),  xhat = (y - mean) * rstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256][VEC * 2 + 1];
+  const int vpc = a.C / VEC;                     // vectors per pixel (power of two)
+  const int tpv = vpc >= 256 ? 1 : 256 / vpc;    // threads sharing one channel vector
+  const int nvb = vpc >= 256 ? vpc / 256 : 1;    // channel-vector blocks (grid.y)
+  (void)nvb;
+  const int cv = (vpc >= 256 ? blockIdx.y * 256 : 0) + (threadIdx.x % (vpc >= 256 ? 256 : vpc));
+  const int pl = vpc >= 256 ? 0 : threadIdx.x / vpc;
+  const int c = cv * VEC;
+  float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sc[i] = a.scale[c + i]; sh[i] = a.shift[c + i]; mu[i] = a.mean[c + i]; rs[i] = a.rstd[c + i]; }
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (size_t p = (size_t)blockIdx.x * tpv + pl; p < a.npix; p += (size_t)gridDim.x * tpv) {
+    const size_t v = p * vpc + cv;
+    float g[VEC], y[VEC];
+    EV<T>::unpack(ldv<T>(a.g, v), g);
+    EV<T>::unpack(ldv<T>(a.y, v), y);
+    if (a.mask == 2) {
+      float o[VEC];
+      EV<T>::unpack(ldv<T>(a.out, v), o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
+    } else if (a.mask == 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], sc[i], sh[i]) > 0.f)) g[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s1[i] += g[i]; s2[i] += g[i] * (y[i] - mu[i]) * rs[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[threadIdx.x][i] = s1[i]; red[threadIdx.x][VEC + i] = s2[i]; }
+  __syncthreads();
+  if (pl == 0) {
+    for (int k = 1; k < tpv; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s1[i] += red[threadIdx.x + k * vpc][i]; s2[i] += red[threadIdx.x + k * vpc][VEC + i]; }
+    float* o = a.slab + ((size_t)blockIdx.x * a.C + c) * 2;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { o[2 * i] = s1[i]; o[2 * i + 1] = s2[i]; }
+  }
+}
+hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  const int VEC = dtype == DT_F32 ? 4 : 8;
+  const int vpc = a.C / VEC;
+  dim3 grid(a.rows, vpc >= 256 ? vpc / 256 : 1);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
+  __shared__ double red[32][33][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < a.C)
+    for (int r = rl; r < a.rows; r += 32) {
+      const float2 v = *(const float2*)(a.slab + ((size_t)r * a.C + c) * 2);
+      s1 += (double)v.x; s2 += (double)v.y;
+    }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && c < a.C) {
+    for (int r = 1; r < 32; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    a.dbeta[c] += (float)s1;
+    a.dgamma[c] += (float)s2;
+    a.coef[2 * c] = (float)(s1 / (double)a.npix);
+    a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
+  }
+}
+hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
+// dy = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+  constexpr int VEC = EV<T>::VEC;
+  const int vpc = a.C / VEC;
+  const size_t nvec = a.npix * (size_t)vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(v % vpc) * VEC;
+    float g[VEC], y[VEC];
+    EV<T>::unpack(ldv<T>(a.g, v), g);
+    EV<T>::unpack(ldv<T>(a.y, v), y);
+    if (a.mask == 2) {
+      float o[VEC];
+      EV<T>::unpack(ldv<T>(a.out, v), o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
+    } else if (a.mask == 1) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], a.scale[c + i], a.shift[c + i]) > 0.f)) g[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xh = (y[i] - a.mean[c + i]) * a.rstd[c + i];
+      g[i] = a.gamma[c + i] * a.rstd[c + i] * (g[i] - a.coef[2 * (c + i)] - xh * a.coef[2 * (c + i) + 1]);
+    }
+    stv<T>(a.dy, v, EV<T>::pack(g));
+  }
+}
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  const size_t nvec = a.npix * (size_t)(a.C / (dtype == DT_F32 ? 4 : 8));
+  const int g = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ gradient plumbing
+template <typename T>
+__global__ __launch_bounds__(256) void masked_accum_kernel(void* dst, const void* g, const void* om, size_t nvec) {
+  constexpr int VEC = EV<T>::VEC;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    float d[VEC], x[VEC];
+    EV<T>::unpack(ldv<T>(dst, v), d);
+    EV<T>::unpack(ldv<T>(g, v), x);
+    if (om) {
+      float o[VEC];
+      EV<T>::unpack(ldv<T>(om, v), o);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) x[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] += x[i];
+    stv<T>(dst, v, EV<T>::pack(d));
+  }
+}
+hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n, hipStream_t st) {
+  const size_t nvec = n / (dtype == DT_F32 ? 4 : 8);
+  const int gr = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(masked_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec);
+  else hipLaunchKernelGGL(masked_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const void* src, int N, int H, int W, int C) {
+  constexpr int VEC = EV<T>::VEC;
+  const int vpc = C / VEC;
+  const size_t nvec = (size_t)N * H * W * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    float d[VEC];
+    EV<T>::unpack(ldv<T>(dst, v), d);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float s[VEC];
+        const size_t sv = (((size_t)n * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * vpc + cv;
+        EV<T>::unpack(ldv<T>(src, sv), s);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] += s[i];
+      }
+    stv<T>(dst, v, EV<T>::pack(d));
+  }
+}
+hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C, hipStream_t st) {
+  const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
+  const int gr = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pool2x2_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C);
+  else hipLaunchKernelGGL(pool2x2_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C);
+  return hipGetLastError();
+}
+
+// bias gradient: out[c] += sum_pixels g[pixel][c]   (few channels; one atomic per block and channel)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const void* g, size_t npix, int Cstride, int C, float* out) {
+  __shared__ float red[256];
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+      if (sizeof(T) == 4) s += ((const float*)g)[p * Cstride + c];
+      else s += __uint_as_float((unsigned)((const bf16_t*)g)[p * Cstride + c] << 16);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out + c, red[0]);
+    __syncthreads();
+  }
+}
+hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride, int C, float* out, hipStream_t st) {
+  const int gr = grid_for(npix, 256, 512);
+  if (dtype == DT_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
+  else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ maxpool 3x3 s2 p1
+// Ties resolve to the first maximum in (row, column) scan order, as torch's CPU kernel does.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* out, int N, int H, int W, int C) {
+  constexpr int VEC = EV<T>::VEC;
+  const int vpc = C / VEC, OH = H / 2, OW = W / 2;
+  const size_t nvec = (size_t)N * OH * OW * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    float m[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+    for (int r = 0; r < 3; ++r) {
+      const int iy = 2 * oy - 1 + r;
+      if (iy < 0 || iy >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int ix = 2 * ox - 1 + s;
+        if (ix < 0 || ix >= W) continue;
+        float x[VEC];
+        EV<T>::unpack(ldv<T>(in, (((size_t)n * H + iy) * W + ix) * vpc + cv), x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) if (x[i] > m[i] || x[i] != x[i]) m[i] = x[i];
+      }
+    }
+    stv<T>(out, v, EV<T>::pack(m));
+  }
+}
+hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H, int W, int C, hipStream_t st) {
+  const size_t nvec = (size_t)N * (H / 2) * (W / 2) * (C / (dtype == DT_F32 ? 4 : 8));
+  const int gr = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, out, N, H, W, C);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, out, N, H, W, C);
+  return hipGetLastError();
+}
+
+// gather form: every input pixel re-derives, for each of the <=4 windows that cover it, whether it
+// is that window's first maximum; no atomics, deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const void* gout, void* gin, int N, int H, int W, int C) {
+  constexpr int VEC = EV<T>::VEC;
+  const int vpc = C / VEC, OH = H / 2, OW = W / 2;
+  const size_t nvec = (size_t)N * H * W * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const int n = (int)(p / H);
+    float acc[VEC], gi[VEC];
+    EV<T>::unpack(ldv<T>(gin, v), gi);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy >= OH) continue;
+      for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox >= OW) continue;
+        // first maximum of window (oy, ox)
+        float m[VEC]; int arg[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { m[i] = -INFINITY; arg[i] = -1; }
+        for (int r = 0; r < 3; ++r) {
+          const int yy = 2 * oy - 1 + r;
+          if (yy < 0 || yy >= H) continue;
+          for (int s = 0; s < 3; ++s) {
+            const int xx = 2 * ox - 1 + s;
+            if (xx < 0 || xx >= W) continue;
+            float x[VEC];
+            EV<T>::unpack(ldv<T>(in, (((size_t)n * H + yy) * W + xx) * vpc + cv), x);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) if (x[i] > m[i] || x[i] != x[i]) { m[i] = x[i]; arg[i] = yy * W + xx; }
+          }
+        }
+        float g[VEC];
+        EV<T>::unpack(ldv<T>(gout, (((size_t)n * OH + oy) * OW + ox) * vpc + cv), g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) if (arg[i] == iy * W + ix) acc[i] += g[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) gi[i] += acc[i];
+    stv<T>(gin, v, EV<T>::pack(gi));
+  }
+}
+hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W, int C, hipStream_t st) {
+  const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
+  const int gr = grid_for(nvec, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ stem im2col (7x7 s2 p3, 3 channels)
+// col[n][oy][ox][k], k = (r*7+s)*3+ci for k < 147, zero padded to KP; the (x-mean)/std normalisation
+// of the reference's forward() is fused here (raw 0..255 BGR input).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, void* col, int N, int H, int W, int KP,
+                                                          float m0, float m1, float m2, float i0, float i1, float i2) {
+  constexpr int VEC = EV<T>::VEC;
+  const int OH = H / 2, OW = W / 2, vpr = KP / VEC;
+  const size_t nvec = (size_t)N * OH * OW * vpr;
+  const float mean[3] = {m0, m1, m2}, inv[3] = {i0, i1, i2};
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int kv = (int)(v % vpr);
+    size_t p = v / vpr;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    float x[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int k = kv * VEC + i;
+      float val = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, ci = k - tap * 3;
+        const int r = tap / 7, s = tap - r * 7;
+        const int iy = 2 * oy - 3 + r, ix = 2 * ox - 3 + s;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+          val = (img[(((size_t)n * 3 + ci) * H + iy) * W + ix] - mean[ci]) * inv[ci];
+      }
+      x[i] = val;
+    }
+    stv<T>(col, v, EV<T>::pack(x));
+  }
+}
+hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
+                              const float* mean, const float* stdv, int normalize, hipStream_t st) {
+  const size_t nvec = (size_t)N * (H / 2) * (W / 2) * (KP / (dtype == DT_F32 ? 4 : 8));
+  const int gr = grid_for(nvec, 256);
+  float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
+  if (normalize) for (int i = 0; i < 3; ++i) { m[i] = mean[i]; iv[i] = 1.0f / stdv[i]; }
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Dice loss
+static __device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+static __device__ __forceinline__ float sigmoid_acc(float z) {
+  // exp(logsigmoid(z)) as smp computes it, evaluated without cancellation
+  const float e = expf(-fabsf(z));
+  return z >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+}
+template <typename V> static __device__ __forceinline__ V block_sum(V v, V* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  V s = 0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+// grid: (chunks, C, B)
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a) {
+  __shared__ double dred[4];
+  __shared__ long long ired[4];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* z = a.logits + ((size_t)b * a.C + c) * a.HW;
+  const float* t = a.target + ((size_t)b * a.C + c) * a.HW;
+  double sI = 0, sS = 0, sT = 0;
+  long long tp = 0, np = 0, nt = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.HW; i += (size_t)gridDim.x * blockDim.x) {
+    const float zi = z[i], ti = t[i];
+    const float p = sigmoid_acc(zi);
+    sI += (double)(p * ti); sS += (double)(p + ti); sT += (double)ti;
+    const int pred = sigmoid_acc(zi) > 0.5f;
+    const int tt = (long long)ti != 0;  // .long() truncation as get_stats does
+    tp += pred & tt; np += pred; nt += tt;
+  }
+  sI = block_sum<double>(sI, dred); sS = block_sum<double>(sS, dred); sT = block_sum<double>(sT, dred);
+  tp = block_sum<long long>(tp, ired); np = block_sum<long long>(np, ired); nt = block_sum<long long>(nt, ired);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.sums + c * 3 + 0, sI); atomicAdd(a.sums + c * 3 + 1, sS); atomicAdd(a.sums + c * 3 + 2, sT);
+    if (a.stats) {
+      unsigned long long* s = (unsigned long long*)(a.stats + ((size_t)b * a.C + c) * 4);
+      atomicAdd(s + 0, (unsigned long long)tp);
+      atomicAdd(s + 1, (unsigned long long)(np - tp));
+      atomicAdd(s + 2, (unsigned long long)(nt - tp));
+    }
+  }
+}
+__global__ void dice_finalize_kernel(const DiceArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double loss = 0.0;
+    for (int c = 0; c < a.C; ++c) {
+      const float I = (float)a.sums[c * 3], S = (float)a.sums[c * 3 + 1], T = (float)a.sums[c * 3 + 2];
+      const float score = (2.0f * I) / fmaxf(S, 1e-7f);
+      loss += (T > 0.f) ? (double)(1.0f - score) : 0.0;
+    }
+    *a.loss = (float)(loss / a.C);
+    if (a.stats)
+      for (int i = 0; i < a.B * a.C; ++i) {
+        long long* s = a.stats + (size_t)i * 4;
+        s[3] = (long long)a.HW - s[0] - s[1] - s[2];
+      }
+  }
+}
+hipError_t launch_dice_fwd(const DiceArgs& a, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * 3 * a.C, st);
+  if (e != hipSuccess) return e;
+  if (a.stats) {
+    e = hipMemsetAsync(a.stats, 0, sizeof(long long) * 4 * a.B * a.C, st);
+    if (e != hipSuccess) return e;
+  }
+  int chunks = (int)((a.HW + 256 * 8 - 1) / (256 * 8));
+  if (chunks > 256) chunks = 256;
+  hipLaunchKernelGGL(dice_fwd_kernel, dim3(chunks, a.C, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// dL/dz for every pixel, written as NHWC rows of CP channels (zero beyond C) so that the head's
+// dgrad / wgrad run on the generic conv kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float grad_scale, void* dl, int CP) {
+  const size_t npix = (size_t)a.B * a.HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = p / a.HW, i = p - b * a.HW;
+    for (int c = 0; c < CP; ++c) {
+      float d = 0.f;
+      if (c < a.C) {
+        const float I = (float)a.sums[c * 3], S = (float)a.sums[c * 3 + 1], Tt = (float)a.sums[c * 3 + 2];
+        if (Tt > 0.f) {
+          const float z = a.logits[(b * a.C + c) * a.HW + i], t = a.target[(b * a.C + c) * a.HW + i];
+          const float pr = sigmoid_acc(z);
+          float dscore;  // d(2I / max(S, eps)) / dp
+          if (S > 1e-7f) dscore = (2.0f * t * S - 2.0f * I) / (S * S);
+          else dscore = 2.0f * t / 1e-7f;
+          d = -dscore * pr * (1.0f - pr) * grad_scale / (float)a.C;
+        }
+      }
+      if (sizeof(T) == 4) ((float*)dl)[p * CP + c] = d;
+      else { __bf16 h = (__bf16)d; ((bf16_t*)dl)[p * CP + c] = __builtin_bit_cast(unsigned short, h); }
+    }
+  }
+}
+hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void* dlogits, int CP, hipStream_t st) {
+  const size_t npix = (size_t)a.B * a.HW;
+  const int gr = grid_for(npix, 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(dice_bwd_kernel<float>, dim3(gr), dim3(256), 0, st, a, grad_scale, dlogits, CP);
+  else hipLaunchKernelGGL(dice_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, a, grad_scale, dlogits, CP);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ weight packing
+// master fp32 [taps][O][I]  ->  wT [taps][O][I] (T)  and  wTt [taps][I][OP] (T, transposed, zero padded)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, void* wT, void* wTt, int taps, int O, int I, int OP) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int o = o0 + k, i = i0 + tx;
+    float v = 0.f;
+    if (o < O && i < I) {
+      v = w[((size_t)tap * O + o) * I + i];
+      if (wT) {
+        if (sizeof(T) == 4) ((float*)wT)[((size_t)tap * O + o) * I + i] = v;
+        else { __bf16 h = (__bf16)v; ((bf16_t*)wT)[((size_t)tap * O + o) * I + i] = __builtin_bit_cast(unsigned short, h); }
+      }
+    }
+    tile[k][tx] = v;
+  }
+  __syncthreads();
+  if (wTt)
+    for (int k = ty; k < 32; k += 8) {
+      const int i = i0 + k, o = o0 + tx;
+      if (i < I && o < OP) {
+        const float v = tile[tx][k];
+        if (sizeof(T) == 4) ((float*)wTt)[((size_t)tap * I + i) * OP + o] = v;
+        else { __bf16 h = (__bf16)v; ((bf16_t*)wTt)[((size_t)tap * I + i) * OP + o] = __builtin_bit_cast(unsigned short, h); }
+      }
+    }
+}
+hipError_t launch_pack_weights(int dtype, const float* w, void* wT, void* wTt, int taps, int O, int I, int OP, hipStream_t st) {
+  dim3 grid((I + 31) / 32, (OP + 31) / 32, taps);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, st, w, wT, wTt, taps, O, I, OP);
+  else hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, grid, dim3(256), 0, st, w, wT, wTt, taps, O, I, OP);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ fused optimizers (torch defaults)
+__global__ __launch_bounds__(256) void optim_kernel(const OptArgs a, float bc1, float bc2, float radam_rect, int radam_use) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float p = a.p[i];
+    float g = a.g[i] * a.grad_scale;
+    if (a.wd != 0.f) g = fmaf(a.wd, p, g);
+    if (a.kind == 0) {  // SGD
+      p -= a.lr * g;
+    } else if (a.kind == 2) {  // RMSprop
+      float v = a.alpha * a.v[i] + (1.f - a.alpha) * g * g;
+      a.v[i] = v;
+      p -= a.lr * g / (sqrtf(v) + a.eps);
+    } else {
+      float m = a.m[i] + (g - a.m[i]) * (1.f - a.beta1);  // lerp, as torch does
+      float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+      a.m[i] = m; a.v[i] = v;
+      if (a.kind == 1) {  // Adam
+        const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
+        p -= (a.lr / bc1) * (m / denom);
+      } else {  // RAdam
+        const float mhat = m / bc1;
+        if (radam_use) p -= mhat * a.lr * (sqrtf(bc2) / (sqrtf(v) + a.eps)) * radam_rect;
+        else p -= mhat * a.lr;
+      }
+    }
+    a.p[i] = p;
+  }
+}
+hipError_t launch_optim_step(const OptArgs& a, hipStream_t st) {
+  const double b1t = pow((double)a.beta1, (double)a.step), b2t = pow((double)a.beta2, (double)a.step);
+  const float bc1 = (float)(1.0 - b1t), bc2 = (float)(1.0 - b2t);
+  float rect = 1.f; int use = 0;
+  if (a.kind == 3) {
+    const double rho_inf = 2.0 / (1.0 - (double)a.beta2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * a.step * b2t / (1.0 - b2t);
+    if (rho_t > 5.0) {
+      use = 1;
+      rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+    }
+  }
+  hipLaunchKernelGGL(optim_kernel, dim3(grid_for(a.n, 256)), dim3(256), 0, st, a, bc1, bc2, rect, use);
+  return hipGetLastError();
+}
+
+}  // namespace octseg

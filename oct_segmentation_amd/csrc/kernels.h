@@ -1,0 +1,94 @@
+// Host-side launchers of the gfx950 kernels (all stream-ordered, never synchronise).
+#pragma once
+#include "common.h"
+
+namespace octseg {
+
+// conv_mfma.hip
+size_t conv_lds_bytes(const ConvArgs& a, int BN);
+int conv_num_mtiles(const ConvArgs& a);
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
+
+// wgrad_mfma.hip
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+
+// elementwise.hip -----------------------------------------------------------------------------
+// BatchNorm finalize (training): reduce the [rows][C][2] slab -> mean/var, scale/shift, running stats.
+hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double count, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float* scale, float* shift, float* mean,
+                                    float* rstd, hipStream_t st);
+// eval: scale/shift from the running statistics.
+hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift,
+                                   hipStream_t st);
+
+// out = relu?( y*scale+shift [+ res*rscale+rshift | + res] ) [+ post]   (NHWC, T)
+struct BnActArgs {
+  const void* y; const float* scale; const float* shift;
+  const void* res; const float* rscale; const float* rshift;  // pre-activation residual (nullable)
+  const void* post;                                           // post-activation addend (nullable)
+  void* out; size_t npix; int C; int relu;
+};
+hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st);
+
+// BatchNorm backward.  g = gradient w.r.t. the post value; mask: 0 none, 1 relu(y*scale+shift) > 0,
+// 2 out > 0 (materialised tensor `out`).  Pass 1 writes [rows][C][2] partials (sum dz, sum dz*xhat).
+struct BnBwdArgs {
+  const void* g; const void* y; const void* out;  // out: mask source for mode 2
+  const float* scale; const float* shift; const float* mean; const float* rstd; const float* gamma;
+  size_t npix; int C; int mask;
+  float* slab; int rows;                 // pass 1 output
+  float* dgamma; float* dbeta;           // pass 2 output (fp32 grad arena, accumulated)
+  float* coef;                           // [C][2]: (sum dz / M, sum dz*xhat / M)
+  void* dy;                              // pass 3 output (may alias g)
+};
+hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
+hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st);
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
+
+// dst += g * (mask ? out > 0 : 1)   (residual / skip gradient)
+hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n,
+                               hipStream_t st);
+// dst[n, y, x, c] += sum_{2x2} src[n, 2y+dy, 2x+dx, c]   (gradient of nearest x2 upsample)
+hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C,
+                                hipStream_t st);
+// per-channel sum over pixels of a NHWC T tensor -> out[c] += sum (bias gradients)
+hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride, int C, float* out,
+                              hipStream_t st);
+
+// maxpool 3x3 s2 p1 (NHWC T)
+hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H, int W, int C,
+                              hipStream_t st);
+hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W,
+                              int C, hipStream_t st);
+
+// stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the 7x7 s2 p3 conv
+hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
+                              const float* mean, const float* stdv, int normalize, hipStream_t st);
+
+// Dice loss (multilabel, from logits) + confusion counts, logits/target NCHW f32
+struct DiceArgs {
+  const float* logits; const float* target; int B, C; size_t HW;
+  double* sums;        // [C][3]: I, S, T   (zeroed by the launcher)
+  long long* stats;    // [B][C][4]: tp, fp, fn, tn (zeroed by the launcher), nullable
+  float* loss;         // scalar
+};
+hipError_t launch_dice_fwd(const DiceArgs& a, hipStream_t st);
+// dL/dz written as NHWC T rows padded to CP channels (zeros beyond C)
+hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void* dlogits, int CP,
+                           hipStream_t st);
+
+// weight packing: master fp32 [taps][O][I] -> T copy and T transposed copy [taps][I][OP] (OP >= O, zero padded)
+hipError_t launch_pack_weights(int dtype, const float* w, void* wT, void* wTt, int taps, int O, int I, int OP,
+                               hipStream_t st);
+
+// fused optimizers over the flat fp32 arenas
+struct OptArgs {
+  float* p; const float* g; float* m; float* v; size_t n;
+  int kind;  // 0 SGD, 1 Adam, 2 RMSprop, 3 RAdam
+  float lr, wd, beta1, beta2, eps, alpha, momentum; int step; float grad_scale;
+};
+hipError_t launch_optim_step(const OptArgs& a, hipStream_t st);
+
+}  // namespace octseg

@@ -1,0 +1,870 @@
+// plan.cpp -- graph builder (torchvision ResNet encoders + smp Unet / UnetPlusPlus / Linknet
+// decoders), workspace planner and the forward / backward executors behind the C ABI.
+//
+// The graph is built once per (arch, encoder, classes, B, H, W, dtype).  Convolutions never see
+// a materialised concat / upsample / BN-apply: a consumer reads `Value`s = (raw tensor, BN id)
+// and applies relu(x*scale+shift) while staging (conv_mfma.hip).  Only residual-block outputs
+// (and LinkNet skip sums) are materialised by bn_act.  Module / parameter names reproduce the
+// smp 0.3.3 + torchvision module tree so that the Python facade can serve a reference
+// state_dict (reference src/predict.py:39-48).
+#include "plan.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+using namespace octseg;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(OCTSEG_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+  } while (0)
+
+static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ================================================================ tap tables / launch geometry
+static void set_taps(signed char* tdy, signed char* tdx, unsigned char* tw, int n, int& ntaps, int& min_dy,
+                     int& min_dx, int& span_y, int& span_x) {
+  ntaps = n;
+  if (n == 0) { min_dy = min_dx = 0; span_y = span_x = 1; return; }
+  int mny = 127, mnx = 127, mxy = -127, mxx = -127;
+  for (int i = 0; i < n; ++i) {
+    mny = std::min(mny, (int)tdy[i]); mxy = std::max(mxy, (int)tdy[i]);
+    mnx = std::min(mnx, (int)tdx[i]); mxx = std::max(mxx, (int)tdx[i]);
+  }
+  (void)tw;
+  min_dy = mny; min_dx = mnx; span_y = mxy - mny + 1; span_x = mxx - mnx + 1;
+}
+
+struct Geom {
+  int R, S, stride, pad;
+  bool transposed;
+  int N, IH, IW, Cin, OH, OW, Cout;
+};
+
+// forward launches: taps + grid + output mapping (sources / weights / destinations filled by caller)
+static void fwd_launches(const Geom& g, std::vector<ConvArgs>& out) {
+  if (!g.transposed) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0;
+    for (int r = 0; r < g.R; ++r)
+      for (int s = 0; s < g.S; ++s) { a.tap_dy[n] = r - g.pad; a.tap_dx[n] = s - g.pad; a.tap_w[n] = r * g.S + s; ++n; }
+    set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+    a.istride = g.stride; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.OH; a.OW = g.OW;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.ostride = 1; a.ooy = a.oox = 0;
+    out.push_back(a);
+  } else {  // ConvTranspose2d k4 s2 p1: one launch per output parity, 2x2 taps each
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        int n = 0;
+        for (int r = 0; r < g.R; ++r) {
+          if (((py + g.pad - r) & 1) != 0) continue;
+          for (int s = 0; s < g.S; ++s) {
+            if (((px + g.pad - s) & 1) != 0) continue;
+            a.tap_dy[n] = (py + g.pad - r) / 2; a.tap_dx[n] = (px + g.pad - s) / 2; a.tap_w[n] = r * g.S + s; ++n;
+          }
+        }
+        set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+        a.istride = 1; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.IH; a.OW = g.IW;  // grid = input grid
+        a.Cin = g.Cin; a.Cout = g.Cout; a.ostride = 2; a.ooy = py; a.oox = px;
+        out.push_back(a);
+      }
+  }
+}
+
+// data-gradient launches: "input" is dy [N,OH,OW,Cout], "output" is dx [N,IH,IW,Cin]
+static void dgrad_launches(const Geom& g, std::vector<ConvArgs>& out) {
+  if (g.transposed) {  // gradient of ConvT = plain conv k4 s2 p1 over dy
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0;
+    for (int r = 0; r < g.R; ++r)
+      for (int s = 0; s < g.S; ++s) { a.tap_dy[n] = r - g.pad; a.tap_dx[n] = s - g.pad; a.tap_w[n] = r * g.S + s; ++n; }
+    set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+    a.istride = 2; a.N = g.N; a.IH = g.OH; a.IW = g.OW; a.OH = g.IH; a.OW = g.IW;
+    a.Cin = g.Cout; a.Cout = g.Cin; a.ostride = 1;
+    out.push_back(a);
+  } else if (g.stride == 1) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0;
+    for (int r = 0; r < g.R; ++r)
+      for (int s = 0; s < g.S; ++s) { a.tap_dy[n] = g.pad - r; a.tap_dx[n] = g.pad - s; a.tap_w[n] = r * g.S + s; ++n; }
+    set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+    a.istride = 1; a.N = g.N; a.IH = g.OH; a.IW = g.OW; a.OH = g.IH; a.OW = g.IW;
+    a.Cin = g.Cout; a.Cout = g.Cin; a.ostride = 1;
+    out.push_back(a);
+  } else {  // stride 2: one launch per input parity
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        int n = 0;
+        for (int r = 0; r < g.R; ++r) {
+          if (((py + g.pad - r) & 1) != 0) continue;
+          for (int s = 0; s < g.S; ++s) {
+            if (((px + g.pad - s) & 1) != 0) continue;
+            a.tap_dy[n] = (py + g.pad - r) / 2; a.tap_dx[n] = (px + g.pad - s) / 2; a.tap_w[n] = r * g.S + s; ++n;
+          }
+        }
+        set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+        a.istride = 1; a.N = g.N; a.IH = g.OH; a.IW = g.OW;
+        a.OH = (g.IH - py + 1) / 2; a.OW = (g.IW - px + 1) / 2;
+        a.Cin = g.Cout; a.Cout = g.Cin; a.ostride = 2; a.ooy = py; a.oox = px;
+        out.push_back(a);
+      }
+  }
+}
+
+static void wgrad_launches(const Geom& g, std::vector<WgradArgs>& out) {
+  if (!g.transposed) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0;
+    for (int r = 0; r < g.R; ++r)
+      for (int s = 0; s < g.S; ++s) { a.tap_dy[n] = r - g.pad; a.tap_dx[n] = s - g.pad; a.tap_w[n] = r * g.S + s; ++n; }
+    set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+    a.istride = g.stride; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.OH; a.OW = g.OW;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.DH = g.OH; a.DW = g.OW; a.dstride = 1;
+    out.push_back(a);
+  } else {
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        int n = 0;
+        for (int r = 0; r < g.R; ++r) {
+          if (((py + g.pad - r) & 1) != 0) continue;
+          for (int s = 0; s < g.S; ++s) {
+            if (((px + g.pad - s) & 1) != 0) continue;
+            a.tap_dy[n] = (py + g.pad - r) / 2; a.tap_dx[n] = (px + g.pad - s) / 2; a.tap_w[n] = r * g.S + s; ++n;
+          }
+        }
+        set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+        a.istride = 1; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.IH; a.OW = g.IW;
+        a.Cin = g.Cin; a.Cout = g.Cout; a.DH = g.OH; a.DW = g.OW; a.dstride = 2; a.doy = py; a.dox = px;
+        out.push_back(a);
+      }
+  }
+}
+
+// ================================================================ graph builder
+namespace {
+
+struct Builder {
+  octseg_plan* P;
+  size_t esz;
+
+  int tensor(int N, int H, int W, int C, bool need_grad = true, bool external = false) {
+    TensorInfo t{N, H, W, C, 0, 0, need_grad, external};
+    P->tensors.push_back(t);
+    return (int)P->tensors.size() - 1;
+  }
+  int param(const std::string& name, int kind, int R, int S, int O, int I, int KP) {
+    ParamInfo p;
+    p.name = name; p.kind = kind; p.R = R; p.S = S; p.O = O; p.I = I; p.KP = KP;
+    p.numel = kind == OCTSEG_P_VEC ? (size_t)O : kind == OCTSEG_P_STEM ? (size_t)O * KP : (size_t)R * S * O * I;
+    p.off = P->param_numel;
+    P->param_numel += (p.numel + 3) / 4 * 4;  // keep 16-byte alignment of every parameter
+    P->params.push_back(p);
+    return (int)P->params.size() - 1;
+  }
+  int bn(const std::string& name, int C, int y, bool lazy) {
+    BNInfo b;
+    b.name = name; b.C = C;
+    b.gamma = param(name + ".weight", OCTSEG_P_VEC, 1, 1, C, 1, 0);
+    b.beta = param(name + ".bias", OCTSEG_P_VEC, 1, 1, C, 1, 0);
+    b.rm_off = P->buffer_numel; P->buffer_numel += C;
+    b.rv_off = P->buffer_numel; P->buffer_numel += C;
+    b.ss_off = 0; b.rows = 0; b.lazy = lazy; b.y = y;
+    const TensorInfo& t = P->tensors[y];
+    b.count = (double)t.N * t.H * t.W;
+    P->bns.push_back(b);
+    return (int)P->bns.size() - 1;
+  }
+
+  // conv (+ optional BN whose statistics the epilogue emits).  Returns Value{raw output, bn}.
+  Value conv(const std::string& name, const std::vector<ConvSrc>& srcs, int Cout, int R, int stride, int pad,
+             const std::string& bn_name, bool bias, bool transposed = false, bool head = false,
+             bool stem = false, bool bn_lazy = true) {
+    ConvLayer L;
+    L.name = name; L.R = R; L.S = R; L.stride = stride; L.pad = pad;
+    L.transposed = transposed; L.head = head; L.stem = stem; L.srcs = srcs; L.Cout = Cout;
+    int Cin = 0;
+    const TensorInfo& t0 = P->tensors[srcs[0].v.t];
+    L.N = t0.N; L.IH = t0.H << srcs[0].up; L.IW = t0.W << srcs[0].up;
+    for (auto& s : srcs) Cin += P->tensors[s.v.t].C;
+    L.Cin = Cin;
+    if (transposed) { L.OH = L.IH * 2; L.OW = L.IW * 2; }
+    else { L.OH = (L.IH + 2 * pad - R) / stride + 1; L.OW = (L.IW + 2 * pad - R) / stride + 1; }
+    if (stem) L.w = param(name + ".weight", OCTSEG_P_STEM, 7, 7, Cout, 3, Cin);
+    else L.w = param(name + ".weight", transposed ? OCTSEG_P_CONVT : OCTSEG_P_CONV, R, R, Cout, Cin, 0);
+    L.b = bias ? param(name + ".bias", OCTSEG_P_VEC, 1, 1, Cout, 1, 0) : -1;
+    L.OP = (Cout + 15) / 16 * 16;
+    L.out = head ? -1 : tensor(L.N, L.OH, L.OW, Cout);
+    L.bn = -1; L.wT_off = L.wTt_off = 0;
+    P->convs.push_back(L);
+    const int ci = (int)P->convs.size() - 1;
+    Op op; op.kind = OP_CONV; op.conv = ci;
+    P->ops.push_back(op);
+    const double taps = (double)R * R;
+    // MACs: every output pixel of a plain conv sees R*S*Cin; ConvT k4 s2 sees 4 taps per output pixel
+    P->fwd_macs += (double)L.N * L.OH * L.OW * Cout * (stem ? 147.0 : (double)Cin * (transposed ? 4.0 : taps));
+    Value v; v.t = L.out; v.bn = -1;
+    if (!bn_name.empty()) {
+      const int b = bn(bn_name, Cout, L.out, bn_lazy);
+      P->convs[ci].bn = b;
+      Op f; f.kind = OP_BN_FIN; f.bn = b;
+      P->ops.push_back(f);
+      v.bn = b;
+    }
+    return v;
+  }
+  // out = relu?(bn(y) + res) + post, materialised
+  int bn_act(Value y, Value res, int post, bool relu) {
+    const TensorInfo& t = P->tensors[y.t];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_BN_ACT; op.y = y; op.res = res; op.post = post; op.relu = relu; op.out = o;
+    P->ops.push_back(op);
+    P->bns[y.bn].lazy = false;
+    if (res.t >= 0 && res.bn >= 0) P->bns[res.bn].lazy = false;
+    return o;
+  }
+  int maxpool(int in) {
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H / 2, t.W / 2, t.C);
+    Op op; op.kind = OP_MAXPOOL; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+};
+
+Value mat(int t) { Value v; v.t = t; v.bn = -1; return v; }
+
+// torchvision ResNet; returns materialised features f1..f5
+std::vector<int> build_resnet(Builder& b, const std::string& enc) {
+  octseg_plan* P = b.P;
+  const bool bottleneck = enc == "resnet50" || enc == "resnet101";
+  int nblocks[4];
+  if (enc == "resnet18") { int v[4] = {2, 2, 2, 2}; memcpy(nblocks, v, sizeof v); }
+  else if (enc == "resnet34" || enc == "resnet50") { int v[4] = {3, 4, 6, 3}; memcpy(nblocks, v, sizeof v); }
+  else { int v[4] = {3, 4, 23, 3}; memcpy(nblocks, v, sizeof v); }
+  const int KP = 160;  // 7*7*3 = 147 padded to a multiple of 32
+  P->col_tensor = b.tensor(P->B, P->H / 2, P->W / 2, KP, false);
+  { Op op; op.kind = OP_STEM_COL; op.out = P->col_tensor; P->ops.push_back(op); }
+  Value ystem = b.conv("encoder.conv1", {{mat(P->col_tensor), 0}}, 64, 1, 1, 0, "encoder.bn1", false, false, false, true);
+  std::vector<int> feats;
+  int f1 = b.bn_act(ystem, Value(), -1, true);
+  feats.push_back(f1);
+  int x = b.maxpool(f1);
+  int inplanes = 64;
+  const int planes_l[4] = {64, 128, 256, 512};
+  for (int li = 0; li < 4; ++li) {
+    const int planes = planes_l[li];
+    const int exp = bottleneck ? 4 : 1;
+    for (int bi = 0; bi < nblocks[li]; ++bi) {
+      const int stride = (bi == 0 && li > 0) ? 2 : 1;
+      const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      const bool ds = (stride != 1) || (inplanes != planes * exp);
+      Value last;
+      if (!bottleneck) {
+        Value v1 = b.conv(pre + ".conv1", {{mat(x), 0}}, planes, 3, stride, 1, pre + ".bn1", false);
+        last = b.conv(pre + ".conv2", {{v1, 0}}, planes, 3, 1, 1, pre + ".bn2", false);
+      } else {
+        Value v1 = b.conv(pre + ".conv1", {{mat(x), 0}}, planes, 1, 1, 0, pre + ".bn1", false);
+        Value v2 = b.conv(pre + ".conv2", {{v1, 0}}, planes, 3, stride, 1, pre + ".bn2", false);
+        last = b.conv(pre + ".conv3", {{v2, 0}}, planes * 4, 1, 1, 0, pre + ".bn3", false);
+      }
+      Value res = mat(x);
+      if (ds) res = b.conv(pre + ".downsample.0", {{mat(x), 0}}, planes * exp, 1, stride, 0, pre + ".downsample.1", false);
+      x = b.bn_act(last, res, -1, true);
+      inplanes = planes * exp;
+    }
+    feats.push_back(x);
+  }
+  return feats;  // f1 (S/2) .. f5 (S/32)
+}
+
+Value unet_block(Builder& b, const std::string& pre, Value x, const std::vector<Value>& skips, int cout) {
+  std::vector<ConvSrc> srcs;
+  srcs.push_back({x, 1});
+  for (auto& s : skips) srcs.push_back({s, 0});
+  Value v1 = b.conv(pre + ".conv1.0", srcs, cout, 3, 1, 1, pre + ".conv1.1", false);
+  return b.conv(pre + ".conv2.0", {{v1, 0}}, cout, 3, 1, 1, pre + ".conv2.1", false);
+}
+
+}  // namespace
+
+static std::string lower(const char* s) {
+  std::string r(s ? s : "");
+  for (auto& c : r) c = (char)tolower((unsigned char)c);
+  return r;
+}
+
+static int build_plan(octseg_plan* P) {
+  Builder b{P, dtype_size(P->dtype)};
+  std::vector<int> f = build_resnet(b, P->encoder);  // f[0]=f1 .. f[4]=f5
+  std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
+  std::vector<int> ench;
+  for (int t : fr) ench.push_back(P->tensors[t].C);
+  const int dec[5] = {256, 128, 64, 32, 16};
+  Value x;
+  int head_k = 3;
+  if (P->arch == "unet") {
+    x = mat(fr[0]);
+    for (int i = 0; i < 5; ++i) {
+      std::vector<Value> skips;
+      if (i < 4) skips.push_back(mat(fr[i + 1]));
+      x = unet_block(b, "decoder.blocks." + std::to_string(i), x, skips, dec[i]);
+    }
+  } else if (P->arch == "unetplusplus") {
+    // smp UnetPlusPlusDecoder
+    std::vector<int> skip_ch(ench.begin() + 1, ench.end());
+    skip_ch.push_back(0);
+    std::map<std::string, Value> dense;
+    auto key = [](int d, int l) { return "x_" + std::to_string(d) + "_" + std::to_string(l); };
+    const int depth = 4;
+    for (int layer = 0; layer < 4; ++layer) {
+      for (int d = 0; d < depth - layer; ++d) {
+        if (layer == 0) {
+          const int cout = d == 0 ? dec[0] : skip_ch[d];
+          dense[key(d, d)] = unet_block(b, "decoder.blocks." + key(d, d), mat(fr[d]), {mat(fr[d + 1])}, cout);
+        } else {
+          const int li = d + layer;
+          std::vector<Value> cat;
+          for (int idx = d + 1; idx <= li; ++idx) cat.push_back(dense[key(idx, li)]);
+          cat.push_back(mat(fr[li + 1]));
+          const int cout = d == 0 ? dec[li] : skip_ch[li];
+          dense[key(d, li)] = unet_block(b, "decoder.blocks." + key(d, li), dense[key(d, li - 1)], cat, cout);
+        }
+      }
+    }
+    x = unet_block(b, "decoder.blocks." + key(0, depth), dense[key(0, depth - 1)], {}, dec[4]);
+  } else if (P->arch == "linknet") {
+    head_k = 1;
+    std::vector<int> ch = ench;
+    ch.push_back(32);
+    x = mat(fr[0]);
+    for (int i = 0; i < 5; ++i) {
+      const std::string pre = "decoder.blocks." + std::to_string(i) + ".block";
+      const int cin = ch[i], mid = cin / 4, cout = ch[i + 1];
+      Value v1 = b.conv(pre + ".0.0", {{x, 0}}, mid, 1, 1, 0, pre + ".0.1", false);
+      Value v2 = b.conv(pre + ".1.0", {{v1, 0}}, mid, 4, 2, 1, pre + ".1.1", true, true);
+      Value v3 = b.conv(pre + ".2.0", {{v2, 0}}, cout, 1, 1, 0, pre + ".2.1", false);
+      if (i < 4) x = mat(b.bn_act(v3, Value(), fr[i + 1], true));
+      else x = v3;
+    }
+  } else {
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet)");
+  }
+  b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
+
+  // ---------------- workspace layout ----------------
+  const size_t esz = dtype_size(P->dtype);
+  size_t off = 0;
+  P->act_begin = off;
+  for (auto& t : P->tensors) { t.off = off; off += align_up((size_t)t.N * t.H * t.W * t.C * esz); }
+  P->act_end = off;
+  P->grad_begin = off;
+  for (auto& t : P->tensors)
+    if (t.need_grad) { t.goff = off; off += align_up((size_t)t.N * t.H * t.W * t.C * esz); }
+  P->grad_end = off;
+  for (auto& bn : P->bns) { bn.ss_off = off; off += align_up((size_t)bn.C * 6 * sizeof(float)); }
+  size_t slab = 0, tmp = 0;
+  for (auto& L : P->convs) {
+    L.wT_off = off; off += align_up((size_t)L.R * L.S * L.Cout * L.Cin * esz);
+    if (L.stem) L.wT_off = L.wT_off;  // stem weight is [O][KP] = one tap, same size formula below
+    L.wTt_off = off; off += align_up((size_t)L.R * L.S * L.Cin * L.OP * esz);
+    if (L.bn >= 0) {
+      Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
+      if (L.stem) { g.R = g.S = 1; g.pad = 0; }
+      std::vector<ConvArgs> la;
+      fwd_launches(g, la);
+      int rows = 0;
+      for (auto& a : la) rows += conv_num_mtiles(a);
+      P->bns[L.bn].rows = rows;
+      slab = std::max(slab, (size_t)rows * L.Cout * 2 * sizeof(float));
+    }
+    for (auto& s : L.srcs)
+      if (s.up) tmp = std::max(tmp, (size_t)L.N * L.IH * L.IW * P->tensors[s.v.t].C * esz);
+  }
+  // the BN backward reduce uses up to 1024 slab rows
+  for (auto& bn : P->bns) slab = std::max(slab, (size_t)1024 * bn.C * 2 * sizeof(float));
+  P->slab_off = off; P->slab_bytes = slab; off += align_up(slab);
+  P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
+  P->dlogits_C = 16;
+  P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
+  P->dice_off = off; off += align_up((size_t)P->classes * 3 * sizeof(double));
+  P->ws_bytes = off;
+  return OCTSEG_OK;
+}
+
+// ================================================================ execution helpers
+namespace {
+
+struct Exec {
+  octseg_plan* P;
+  const float* params;
+  float* grads;
+  float* buffers;
+  char* ws;
+  hipStream_t st;
+  int train;
+
+  void* act(int t) const { return ws + P->tensors[t].off; }
+  void* grad(int t) const { return ws + P->tensors[t].goff; }
+  float* ss(int bn) const { return (float*)(ws + P->bns[bn].ss_off); }
+  float* bn_scale(int bn) const { return ss(bn); }
+  float* bn_shift(int bn) const { return ss(bn) + P->bns[bn].C; }
+  float* bn_mean(int bn) const { return ss(bn) + 2 * P->bns[bn].C; }
+  float* bn_rstd(int bn) const { return ss(bn) + 3 * P->bns[bn].C; }
+  float* bn_coef(int bn) const { return ss(bn) + 4 * P->bns[bn].C; }
+
+  Geom geom(const ConvLayer& L) const {
+    Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
+    if (L.stem) { g.R = g.S = 1; g.pad = 0; }
+    return g;
+  }
+  int fill_srcs(const ConvLayer& L, SrcDesc* src) const {
+    int c0 = 0, n = 0;
+    for (auto& s : L.srcs) {
+      const TensorInfo& t = P->tensors[s.v.t];
+      SrcDesc d;
+      d.ptr = act(s.v.t);
+      d.scale = s.v.bn >= 0 ? bn_scale(s.v.bn) : nullptr;
+      d.shift = s.v.bn >= 0 ? bn_shift(s.v.bn) : nullptr;
+      d.C = t.C; d.c0 = c0; d.H = t.H; d.W = t.W; d.up = s.up; d.relu = s.v.bn >= 0 ? 1 : 0;
+      src[n++] = d;
+      c0 += t.C;
+    }
+    return n;
+  }
+};
+
+}  // namespace
+
+static int pack_all_weights(Exec& E) {
+  octseg_plan* P = E.P;
+  for (auto& L : P->convs) {
+    const ParamInfo& w = P->params[L.w];
+    const int taps = L.stem ? 1 : L.R * L.S;
+    const int O = L.Cout, I = L.Cin;
+    void* wT = E.ws + L.wT_off;
+    void* wTt = (L.stem) ? nullptr : (void*)(E.ws + L.wTt_off);  // the stem has no data gradient
+    if (P->dtype == DT_F32 && wTt == nullptr) continue;           // f32 forward reads the master copy
+    HIPCHK(launch_pack_weights(P->dtype, E.params + w.off, P->dtype == DT_F32 ? nullptr : wT, wTt, taps, O, I, L.OP, E.st));
+  }
+  return OCTSEG_OK;
+}
+
+static const void* fwd_weight(const Exec& E, const ConvLayer& L) {
+  if (E.P->dtype == DT_F32) return E.params + E.P->params[L.w].off;
+  return E.ws + L.wT_off;
+}
+
+static int run_forward(Exec& E, const float* image, float* logits, int normalize, const float* mean, const float* stdv) {
+  octseg_plan* P = E.P;
+  int rc = pack_all_weights(E);
+  if (rc) return rc;
+  for (auto& op : P->ops) {
+    switch (op.kind) {
+      case OP_STEM_COL: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, E.st));
+        break;
+      }
+      case OP_CONV: {
+        const ConvLayer& L = P->convs[op.conv];
+        std::vector<ConvArgs> la;
+        fwd_launches(E.geom(L), la);
+        int row0 = 0;
+        for (auto& a : la) {
+          a.nsrc = E.fill_srcs(L, a.src);
+          a.W = fwd_weight(E, L);
+          a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
+          a.ndst = 1;
+          DstDesc d;
+          if (L.head) { d.ptr = logits; d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW; }
+          else { d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE; }
+          a.dst[0] = d;
+          a.stat_slab = (L.bn >= 0 && E.train) ? (float*)(E.ws + P->slab_off) : nullptr;
+          a.slab_row0 = row0;
+          row0 += conv_num_mtiles(a);
+          HIPCHK(launch_conv(P->dtype, a, E.st));
+        }
+        break;
+      }
+      case OP_BN_FIN: {
+        const BNInfo& b = P->bns[op.bn];
+        const float* gamma = E.params + P->params[b.gamma].off;
+        const float* beta = E.params + P->params[b.beta].off;
+        if (E.train)
+          HIPCHK(launch_bn_finalize_train((const float*)(E.ws + P->slab_off), b.rows, b.C, b.count, gamma, beta,
+                                          E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f, 1e-5f, E.bn_scale(op.bn),
+                                          E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), E.st));
+        else
+          HIPCHK(launch_bn_finalize_eval(b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 1e-5f,
+                                         E.bn_scale(op.bn), E.bn_shift(op.bn), E.st));
+        break;
+      }
+      case OP_BN_ACT: {
+        const TensorInfo& t = P->tensors[op.out];
+        BnActArgs a;
+        memset(&a, 0, sizeof(a));
+        a.y = E.act(op.y.t); a.scale = E.bn_scale(op.y.bn); a.shift = E.bn_shift(op.y.bn);
+        if (op.res.t >= 0) {
+          a.res = E.act(op.res.t);
+          if (op.res.bn >= 0) { a.rscale = E.bn_scale(op.res.bn); a.rshift = E.bn_shift(op.res.bn); }
+        }
+        if (op.post >= 0) a.post = E.act(op.post);
+        a.out = E.act(op.out); a.npix = (size_t)t.N * t.H * t.W; a.C = t.C; a.relu = op.relu;
+        HIPCHK(launch_bn_act(P->dtype, a, E.st));
+        break;
+      }
+      case OP_MAXPOOL: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_maxpool_fwd(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, E.st));
+        break;
+      }
+    }
+  }
+  return OCTSEG_OK;
+}
+
+// BN backward of BN `bn` over raw tensor y: g -> dy (written to grad(y))
+static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out_mask) {
+  octseg_plan* P = E.P;
+  const BNInfo& b = P->bns[bn];
+  const TensorInfo& t = P->tensors[b.y];
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.y = E.act(b.y); a.out = out_mask;
+  a.scale = E.bn_scale(bn); a.shift = E.bn_shift(bn); a.mean = E.bn_mean(bn); a.rstd = E.bn_rstd(bn);
+  a.gamma = E.params + P->params[b.gamma].off;
+  a.npix = (size_t)t.N * t.H * t.W; a.C = b.C; a.mask = mask;
+  a.slab = (float*)(E.ws + P->slab_off);
+  const int VEC = P->dtype == DT_F32 ? 4 : 8;
+  const int vpc = b.C / VEC;
+  const int tpv = vpc >= 256 ? 1 : 256 / vpc;
+  size_t rows = (a.npix + tpv - 1) / tpv;
+  if (rows > 1024) rows = 1024;
+  a.rows = (int)rows;
+  a.dgamma = E.grads + P->params[b.gamma].off;
+  a.dbeta = E.grads + P->params[b.beta].off;
+  a.coef = E.bn_coef(bn);
+  a.dy = E.grad(b.y);
+  HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
+  HIPCHK(launch_bn_bwd_finalize(a, E.st));
+  HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
+  return OCTSEG_OK;
+}
+
+static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
+  octseg_plan* P = E.P;
+  const size_t esz = dtype_size(P->dtype);
+  const Geom g = E.geom(L);
+  // bias gradient
+  if (L.b >= 0)
+    HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, E.st));
+  // weight gradient
+  {
+    std::vector<WgradArgs> lw;
+    wgrad_launches(g, lw);
+    for (auto& a : lw) {
+      a.nsrc = E.fill_srcs(L, a.src);
+      a.dy = dy; a.dyC = dyC;
+      a.dW = E.grads + P->params[L.w].off;
+      HIPCHK(launch_wgrad(P->dtype, a, E.st));
+    }
+  }
+  // data gradient
+  bool any = false;
+  for (auto& s : L.srcs) any = any || P->tensors[s.v.t].need_grad;
+  if (!any) return OCTSEG_OK;
+  std::vector<ConvArgs> ld;
+  dgrad_launches(g, ld);
+  // destinations: the forward sources' gradient buffers; upsampled sources go through a temp
+  DstDesc dst[MAX_SRC];
+  int nd = 0, c0 = 0;
+  int up_src = -1;
+  for (size_t i = 0; i < L.srcs.size(); ++i) {
+    const TensorInfo& t = P->tensors[L.srcs[i].v.t];
+    DstDesc d;
+    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW;
+    if (L.srcs[i].up) {
+      d.ptr = E.ws + P->tmp_off;
+      up_src = (int)i;
+      HIPCHK(hipMemsetAsync(d.ptr, 0, (size_t)L.N * L.IH * L.IW * t.C * esz, E.st));
+    } else {
+      d.ptr = E.grad(L.srcs[i].v.t);
+    }
+    dst[nd++] = d;
+    c0 += t.C;
+  }
+  for (auto& a : ld) {
+    SrcDesc s;
+    s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
+    a.src[0] = s; a.nsrc = 1;
+    a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of wTt are zero
+    a.W = E.ws + L.wTt_off;
+    for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
+    a.ndst = nd;
+    a.out_mode = OUT_ACCUM;
+    a.bias = nullptr; a.stat_slab = nullptr;
+    HIPCHK(launch_conv(P->dtype, a, E.st));
+  }
+  if (up_src >= 0) {
+    const TensorInfo& t = P->tensors[L.srcs[up_src].v.t];
+    HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(L.srcs[up_src].v.t), E.ws + P->tmp_off, t.N, t.H, t.W, t.C, E.st));
+  }
+  return OCTSEG_OK;
+}
+
+static int run_backward(Exec& E, const float* logits, const float* target, float grad_scale) {
+  octseg_plan* P = E.P;
+  HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
+  HIPCHK(hipMemsetAsync(E.ws + P->grad_begin, 0, P->grad_end - P->grad_begin, E.st));
+  // dL/dlogits (NHWC, padded channels)
+  DiceArgs da;
+  memset(&da, 0, sizeof(da));
+  da.logits = logits; da.target = target; da.B = P->B; da.C = P->classes; da.HW = (size_t)P->H * P->W;
+  da.sums = (double*)(E.ws + P->dice_off);
+  HIPCHK(launch_dice_bwd(P->dtype, da, grad_scale, E.ws + P->dlogits_off, P->dlogits_C, E.st));
+  int rc;
+  for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
+    const Op& op = P->ops[oi];
+    switch (op.kind) {
+      case OP_STEM_COL: break;
+      case OP_CONV: {
+        const ConvLayer& L = P->convs[op.conv];
+        if (L.head) rc = conv_backward(E, L, E.ws + P->dlogits_off, P->dlogits_C);
+        else rc = conv_backward(E, L, E.grad(L.out), L.Cout);
+        if (rc) return rc;
+        break;
+      }
+      case OP_BN_FIN: {
+        const BNInfo& b = P->bns[op.bn];
+        if (b.lazy) {  // consumers accumulated d/d relu(bn(y)) into grad(y): turn it into dy in place
+          rc = bn_backward(E, op.bn, E.grad(b.y), 1, nullptr);
+          if (rc) return rc;
+        }
+        break;
+      }
+      case OP_BN_ACT: {
+        const TensorInfo& t = P->tensors[op.out];
+        const void* G = E.grad(op.out);
+        const size_t n = (size_t)t.N * t.H * t.W * t.C;
+        // main branch: with a post-add the relu mask must come from bn(y) itself
+        const int mask = !op.relu ? 0 : (op.post >= 0 ? 1 : 2);
+        rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out));
+        if (rc) return rc;
+        if (op.res.t >= 0) {
+          if (op.res.bn >= 0) {
+            rc = bn_backward(E, op.res.bn, G, op.relu ? 2 : 0, E.act(op.out));
+            if (rc) return rc;
+          } else if (P->tensors[op.res.t].need_grad) {
+            HIPCHK(launch_masked_accum(P->dtype, E.grad(op.res.t), G, op.relu ? E.act(op.out) : nullptr, n, E.st));
+          }
+        }
+        if (op.post >= 0 && P->tensors[op.post].need_grad)
+          HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, E.st));
+        break;
+      }
+      case OP_MAXPOOL: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_maxpool_bwd(P->dtype, E.act(op.in), E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, E.st));
+        break;
+      }
+    }
+  }
+  return OCTSEG_OK;
+}
+
+// ================================================================ C ABI
+extern "C" {
+
+int octseg_version(void) { return 100; }
+const char* octseg_last_error(void) { return g_err.c_str(); }
+
+int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
+  if (!d || !out) return fail(OCTSEG_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (d->dtype != OCTSEG_F32 && d->dtype != OCTSEG_BF16) return fail(OCTSEG_BAD_DTYPE, "dtype must be f32 or bf16");
+  if (d->height <= 0 || d->width <= 0 || d->height % 32 != 0 || d->width % 32 != 0) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.",
+             d->height, d->width);
+    return fail(OCTSEG_BAD_SHAPE, buf);
+  }
+  if (d->batch <= 0 || d->classes <= 0 || d->classes > 16) return fail(OCTSEG_BAD_SHAPE, "batch > 0 and 1 <= classes <= 16 required");
+  const std::string enc = lower(d->encoder);
+  if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101")
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101)");
+  octseg_plan* P = new octseg_plan();
+  P->arch = lower(d->arch); P->encoder = enc; P->classes = d->classes;
+  P->B = d->batch; P->H = d->height; P->W = d->width; P->dtype = d->dtype;
+  const int rc = build_plan(P);
+  if (rc) { delete P; return rc; }
+  *out = P;
+  return OCTSEG_OK;
+}
+int octseg_plan_destroy(octseg_plan* p) { delete p; return OCTSEG_OK; }
+size_t octseg_plan_workspace_bytes(const octseg_plan* p) { return p ? p->ws_bytes : 0; }
+size_t octseg_plan_param_numel(const octseg_plan* p) { return p ? p->param_numel : 0; }
+size_t octseg_plan_buffer_numel(const octseg_plan* p) { return p ? p->buffer_numel : 0; }
+int octseg_plan_num_params(const octseg_plan* p) { return p ? (int)p->params.size() : 0; }
+int octseg_plan_num_bn(const octseg_plan* p) { return p ? (int)p->bns.size() : 0; }
+double octseg_plan_fwd_macs(const octseg_plan* p) { return p ? p->fwd_macs : 0.0; }
+
+int octseg_plan_param_info(const octseg_plan* p, int i, octseg_param_info* o) {
+  if (!p || !o || i < 0 || i >= (int)p->params.size()) return fail(OCTSEG_BAD_ARG, "param index out of range");
+  const ParamInfo& q = p->params[i];
+  memset(o, 0, sizeof(*o));
+  snprintf(o->name, sizeof o->name, "%s", q.name.c_str());
+  o->kind = q.kind; o->R = q.R; o->S = q.S; o->O = q.O; o->I = q.I; o->KP = q.KP; o->offset = q.off; o->numel = q.numel;
+  return OCTSEG_OK;
+}
+int octseg_plan_bn_info(const octseg_plan* p, int i, octseg_bn_info* o) {
+  if (!p || !o || i < 0 || i >= (int)p->bns.size()) return fail(OCTSEG_BAD_ARG, "bn index out of range");
+  const BNInfo& b = p->bns[i];
+  memset(o, 0, sizeof(*o));
+  snprintf(o->name, sizeof o->name, "%s", b.name.c_str());
+  o->C = b.C; o->mean_offset = b.rm_off; o->var_offset = b.rv_off;
+  return OCTSEG_OK;
+}
+
+int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void* workspace, const float* image,
+                       float* logits, int normalize, const float* mean, const float* stdv, int train, void* stream) {
+  if (!p || !params || !buffers || !workspace || !image || !logits) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (normalize && (!mean || !stdv)) return fail(OCTSEG_BAD_ARG, "normalize=1 needs mean/std");
+  Exec E{p, params, nullptr, buffers, (char*)workspace, (hipStream_t)stream, train};
+  return run_forward(E, image, logits, normalize, mean, stdv);
+}
+
+int octseg_dice_forward(octseg_plan* p, void* workspace, const float* logits, const float* target, float* loss,
+                        long long* stats, void* stream) {
+  if (!p || !workspace || !logits || !target || !loss) return fail(OCTSEG_BAD_ARG, "null argument");
+  DiceArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = logits; a.target = target; a.B = p->B; a.C = p->classes; a.HW = (size_t)p->H * p->W;
+  a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss;
+  HIPCHK(launch_dice_fwd(a, (hipStream_t)stream));
+  return OCTSEG_OK;
+}
+
+int octseg_net_backward(octseg_plan* p, const float* params, float* grads, void* workspace, const float* logits,
+                        const float* target, float grad_scale, void* stream) {
+  if (!p || !params || !grads || !workspace || !logits || !target) return fail(OCTSEG_BAD_ARG, "null argument");
+  Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
+  return run_backward(E, logits, target, grad_scale);
+}
+
+int octseg_optim_step(int kind, float* params, const float* grads, float* m, float* v, size_t numel, float lr,
+                      float wd, int step, float grad_scale, void* stream) {
+  if (!params || !grads) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (kind < 0 || kind > 3) return fail(OCTSEG_BAD_ARG, "optimizer kind must be 0..3");
+  if ((kind == 1 || kind == 3) && (!m || !v)) return fail(OCTSEG_BAD_ARG, "Adam/RAdam need both state arenas");
+  if (kind == 2 && !v) return fail(OCTSEG_BAD_ARG, "RMSprop needs the second-moment arena");
+  OptArgs a;
+  memset(&a, 0, sizeof(a));
+  a.p = params; a.g = grads; a.m = m; a.v = v; a.n = numel; a.kind = kind; a.lr = lr; a.wd = wd;
+  a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f; a.alpha = 0.99f; a.momentum = 0.f; a.step = step; a.grad_scale = grad_scale;
+  HIPCHK(launch_optim_step(a, (hipStream_t)stream));
+  return OCTSEG_OK;
+}
+
+// ---------------------------------------------------------------- single-op entry points
+static bool geom_ok(int dtype, int Cin, int Cout, int R, int S, int stride, int transposed) {
+  const int v = dtype == OCTSEG_F32 ? 4 : 8;
+  (void)Cout;
+  if (Cin % v != 0) return false;
+  if (R != S || R < 1 || R > 7) return false;
+  if (stride != 1 && stride != 2) return false;
+  if (transposed && !(R == 4 && stride == 2)) return false;
+  return true;
+}
+size_t octseg_conv2d_scratch_bytes(int dtype, int N, int H, int W, int Cin, int Cout, int R, int S) {
+  (void)N; (void)H; (void)W;
+  const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
+  const int OP = (Cout + 15) / 16 * 16;
+  return align_up((size_t)R * S * Cout * Cin * esz) + align_up((size_t)R * S * Cin * OP * esz) +
+         align_up((size_t)N * H * W * 4 * OP * esz);  // + channel-padded copy of dy for the data gradient
+}
+
+int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float* bias, void* y, int N, int H, int W,
+                          int Cin, int Cout, int R, int S, int stride, int pad, int transposed, void* scratch, void* stream) {
+  if (!geom_ok(dtype, Cin, Cout, R, S, stride, transposed)) return fail(OCTSEG_BAD_SHAPE, "unsupported conv geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
+  const void* wdev = w;
+  if (dtype != OCTSEG_F32) {
+    HIPCHK(launch_pack_weights(dtype, w, scratch, nullptr, R * S, Cout, Cin, Cout, st));
+    wdev = scratch;
+  }
+  (void)esz;
+  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
+  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  std::vector<ConvArgs> la;
+  fwd_launches(g, la);
+  for (auto& a : la) {
+    SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
+    a.src[0] = s; a.nsrc = 1; a.W = wdev; a.bias = bias;
+    DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW;
+    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr;
+    HIPCHK(launch_conv(dtype, a, st));
+  }
+  return OCTSEG_OK;
+}
+
+int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void* dx, int N, int H, int W, int Cin,
+                                int Cout, int R, int S, int stride, int pad, int transposed, void* scratch, void* stream) {
+  const int v = dtype == OCTSEG_F32 ? 4 : 8;
+  if (!geom_ok(dtype, Cin, Cout, R, S, stride, transposed) || Cout % v != 0) return fail(OCTSEG_BAD_SHAPE, "unsupported conv geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
+  const int OP = Cout;  // entry point requires Cout % vec == 0, so dy needs no channel padding
+  char* wTt = (char*)scratch + align_up((size_t)R * S * Cout * Cin * esz);
+  HIPCHK(launch_pack_weights(dtype, w, nullptr, wTt, R * S, Cout, Cin, OP, st));
+  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
+  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  HIPCHK(hipMemsetAsync(dx, 0, (size_t)N * H * W * Cin * esz, st));
+  std::vector<ConvArgs> ld;
+  dgrad_launches(g, ld);
+  for (auto& a : ld) {
+    SrcDesc s; s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = Cout; s.c0 = 0; s.H = g.OH; s.W = g.OW; s.up = 0; s.relu = 0;
+    a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = wTt; a.bias = nullptr;
+    DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W;
+    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_ACCUM; a.stat_slab = nullptr;
+    HIPCHK(launch_conv(dtype, a, st));
+  }
+  return OCTSEG_OK;
+}
+
+int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, float* dw, int N, int H, int W, int Cin,
+                                  int Cout, int R, int S, int stride, int pad, int transposed, void* stream) {
+  const int v = dtype == OCTSEG_F32 ? 4 : 8;
+  if (!geom_ok(dtype, Cin, Cout, R, S, stride, transposed) || Cout % v != 0) return fail(OCTSEG_BAD_SHAPE, "unsupported conv geometry");
+  hipStream_t st = (hipStream_t)stream;
+  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
+  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  HIPCHK(hipMemsetAsync(dw, 0, (size_t)R * S * Cout * Cin * sizeof(float), st));
+  std::vector<WgradArgs> lw;
+  wgrad_launches(g, lw);
+  for (auto& a : lw) {
+    SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
+    a.src[0] = s; a.nsrc = 1; a.dy = dy; a.dyC = Cout; a.dW = dw;
+    HIPCHK(launch_wgrad(dtype, a, st));
+  }
+  return OCTSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// plan.h -- static execution plan of one segmentation network on one GPU.
+#pragma once
+#include <string>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "../../include/octseg.h"
+
+namespace octseg {
+
+struct TensorInfo {
+  int N, H, W, C;
+  size_t off;    // byte offset of the activation in the workspace
+  size_t goff;   // byte offset of its gradient buffer (valid when need_grad)
+  bool need_grad;
+  bool external; // logits / image: not in the workspace
+};
+
+struct Value {   // what a consumer reads: tensor t, optionally through BN `bn` (scale/shift) lazily
+  int t = -1;
+  int bn = -1;
+};
+
+struct ParamInfo {
+  std::string name;
+  int kind, R, S, O, I, KP;
+  size_t off, numel;
+};
+
+struct BNInfo {
+  std::string name;
+  int C;
+  int gamma, beta;          // param indices
+  size_t rm_off, rv_off;    // element offsets in the buffer arena
+  size_t ss_off;            // byte offset in workspace: scale[C] shift[C] mean[C] rstd[C] coef[2C]
+  double count;             // elements per channel of the tensor it normalises
+  int rows;                 // slab rows produced by the conv epilogue
+  bool lazy;                // consumed by conv sources (relu(bn(y))) -> BN backward runs in place
+  int y;                    // tensor it normalises
+};
+
+struct ConvSrc { Value v; int up; };
+
+struct ConvLayer {
+  std::string name;
+  int R, S, stride, pad;
+  bool transposed, head, stem;
+  int Cin, Cout;
+  int N, IH, IW, OH, OW;    // virtual input extent, output extent
+  std::vector<ConvSrc> srcs;
+  int out;                  // tensor id of the raw output (or -1 for the head: external logits)
+  int bn;                   // BN that follows (stats emitted by the epilogue), or -1
+  int w, b;                 // param indices (b = -1: no bias)
+  size_t wT_off, wTt_off;   // byte offsets of the packed compute copies in the workspace
+  int OP;                   // padded K of the dgrad (Cout rounded up to 16)
+};
+
+enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL };
+struct Op {
+  OpKind kind;
+  int conv = -1;   // OP_CONV
+  int bn = -1;     // OP_BN_FIN
+  // OP_BN_ACT: out = relu?(bn(y) + res) + post
+  Value y, res;
+  int post = -1;
+  bool relu = true;
+  int in = -1, out = -1;  // OP_MAXPOOL / OP_BN_ACT / OP_STEM_COL out
+};
+
+}  // namespace octseg
+
+struct octseg_plan {
+  std::string arch, encoder;
+  int classes, B, H, W, dtype;
+  std::vector<octseg::TensorInfo> tensors;
+  std::vector<octseg::ParamInfo> params;
+  std::vector<octseg::BNInfo> bns;
+  std::vector<octseg::ConvLayer> convs;
+  std::vector<octseg::Op> ops;
+  size_t param_numel = 0, buffer_numel = 0;
+  size_t ws_bytes = 0;
+  size_t act_begin = 0, act_end = 0, grad_begin = 0, grad_end = 0;
+  size_t slab_off = 0, slab_bytes = 0;       // BN partial-sum slab (shared, reused per layer)
+  size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
+  size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
+  size_t dice_off = 0;                       // double sums[C][3]
+  int col_tensor = -1;
+  int dlogits_C = 16;
+  double fwd_macs = 0;
+};
