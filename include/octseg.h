@@ -88,6 +88,10 @@ int octseg_plan_param_info(const octseg_plan* plan, int index, octseg_param_info
 int octseg_plan_num_bn(const octseg_plan* plan);
 int octseg_plan_bn_info(const octseg_plan* plan, int index, octseg_bn_info* out);
 double octseg_plan_fwd_macs(const octseg_plan* plan);      /* conv multiply-accumulates of one forward */
+/* test hook: workspace byte offsets of the raw output (NHWC, plan dtype) of conv layer `conv_name`
+ * (module path, e.g. "decoder.blocks.0.conv1.0") and of its gradient; dims = {N,H,W,C}. */
+int octseg_plan_find_tensor(const octseg_plan* plan, const char* conv_name, size_t* act_off,
+                            size_t* grad_off, int* dims);
 
 /* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
  * train=1: batch statistics, running buffers updated, activations kept for backward. */

@@ -43,6 +43,7 @@ SYMBOLS = {
     'octseg_plan_num_bn': (C.c_int, [_P]),
     'octseg_plan_bn_info': (C.c_int, [_P, C.c_int, C.POINTER(BNInfo)]),
     'octseg_plan_fwd_macs': (C.c_double, [_P]),
+    'octseg_plan_find_tensor': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     'octseg_net_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_int, _P]),
     'octseg_dice_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),

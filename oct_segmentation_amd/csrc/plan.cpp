@@ -742,6 +742,20 @@ int octseg_plan_bn_info(const octseg_plan* p, int i, octseg_bn_info* o) {
   return OCTSEG_OK;
 }
 
+// debug / test hook: byte offsets (inside the workspace) of a conv layer's raw output and its gradient
+int octseg_plan_find_tensor(const octseg_plan* p, const char* conv_name, size_t* act_off, size_t* grad_off, int* dims) {
+  if (!p || !conv_name) return fail(OCTSEG_BAD_ARG, "null argument");
+  for (auto& L : p->convs)
+    if (L.name == conv_name && L.out >= 0) {
+      const TensorInfo& t = p->tensors[L.out];
+      if (act_off) *act_off = t.off;
+      if (grad_off) *grad_off = t.goff;
+      if (dims) { dims[0] = t.N; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+      return OCTSEG_OK;
+    }
+  return fail(OCTSEG_BAD_ARG, std::string("no conv layer named ") + conv_name);
+}
+
 int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void* workspace, const float* image,
                        float* logits, int normalize, const float* mean, const float* stdv, int train, void* stream) {
   if (!p || !params || !buffers || !workspace || !image || !logits) return fail(OCTSEG_BAD_ARG, "null argument");

@@ -1,0 +1,310 @@
+"""Plan-level host binding: ``SegNet`` = the MI355X counterpart of
+``smp.create_model(arch, encoder_name, in_channels, classes)`` (reference
+``src/models/smp/model.py:38-44``).
+
+PyTorch is used for device memory only: one flat fp32 parameter arena (+ a
+gradient arena of the same layout), a BN buffer arena and one workspace blob
+per (B, H, W) plan.  All arithmetic happens in ``liboctseg_hip.so``.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+_ARCHS = ('unet', 'unetplusplus', 'linknet')
+_ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101')
+
+
+def get_preprocessing_params(encoder_name, pretrained='imagenet'):
+    """smp.encoders.get_preprocessing_params for the torchvision ResNets (model.py:49)."""
+    if encoder_name not in _ENCODERS:
+        raise KeyError(f'Wrong encoder name `{encoder_name}`, supported encoders: {list(_ENCODERS)}')
+    return {'input_space': 'RGB', 'input_range': [0, 1], 'mean': [0.485, 0.456, 0.406], 'std': [0.229, 0.224, 0.225]}
+
+
+def _dtype_code(dtype):
+    if dtype in (torch.float32, 'fp32', 'f32', 'float32'):
+        return L.F32
+    if dtype in (torch.bfloat16, 'bf16', 'bfloat16'):
+        return L.BF16
+    raise TypeError(f'compute dtype must be float32 or bfloat16, got {dtype}')
+
+
+class _Plan:
+    """RAII wrapper of an ``octseg_plan`` plus its workspace."""
+
+    def __init__(self, arch, encoder, classes, B, H, W, dtype_code):
+        self.handle = C.c_void_p()
+        d = L.NetDesc(arch.encode(), encoder.encode(), classes, B, H, W, dtype_code)
+        rc = L.lib().octseg_plan_create(C.byref(d), C.byref(self.handle))
+        if rc != 0:
+            msg = L.lib().octseg_last_error().decode()
+            if rc == -3:
+                raise KeyError(msg)
+            raise RuntimeError(msg)  # -1: same text as smp's check_input_shape RuntimeError
+        self.workspace = None
+        self.shape = (B, H, W)
+
+    def ws(self, device):
+        if self.workspace is None:
+            n = L.lib().octseg_plan_workspace_bytes(self.handle)
+            self.workspace = torch.empty(n, dtype=torch.uint8, device=device)
+        return self.workspace
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.lib().octseg_plan_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+class _DiceStep(torch.autograd.Function):
+    """Connects the engine's fused forward+Dice to autograd so ``loss.backward()`` (what
+    Lightning does after ``training_step``) fills the parameter arena's ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, arena, net, image, target, normalize, mean, std):
+        logits, loss, stats, plan = net._forward_loss(image, target, normalize, mean, std)
+        ctx.net, ctx.plan, ctx.logits, ctx.target = net, plan, logits, target
+        ctx.mark_non_differentiable(logits, stats)
+        return loss, logits, stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gl, _gs):
+        net = ctx.net
+        g = net._backward(ctx.plan, ctx.logits, ctx.target)
+        return g * gloss, None, None, None, None, None, None
+
+
+class SegNet(nn.Module):
+    """Segmentation network living in ``liboctseg_hip.so``.
+
+    ``forward(x)`` takes NCHW float32 ``[B, 3, H, W]`` on the GPU and returns NCHW float32
+    logits ``[B, classes, H, W]``.  ``state_dict()`` / ``load_state_dict()`` speak the smp /
+    torchvision key names and torch weight layouts of a reference checkpoint.
+    """
+
+    def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
+                 device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
+        super().__init__()
+        a = arch.lower()
+        if a not in _ARCHS:
+            raise KeyError(f'Wrong architecture type `{arch}`. Available options are: {list(_ARCHS)}')
+        if encoder_name not in _ENCODERS:
+            raise KeyError(f'Wrong encoder name `{encoder_name}`, supported encoders: {list(_ENCODERS)}')
+        if in_channels != 3:
+            raise ValueError('the gfx950 stem kernel is specialised for in_channels=3 (the reference always uses 3)')
+        L.lib()  # fail loudly right here when the HIP library is missing
+        self.arch, self.encoder_name, self.classes = a, encoder_name, int(classes)
+        self.dtype_code = _dtype_code(compute_dtype)
+        self.device = torch.device(device)
+        self._plans = {}
+        # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
+        probe = _Plan(a, encoder_name, self.classes, 1, 32, 32, self.dtype_code)
+        lib = L.lib()
+        self.param_table = []
+        for i in range(lib.octseg_plan_num_params(probe.handle)):
+            pi = L.ParamInfo()
+            L.check(lib.octseg_plan_param_info(probe.handle, i, C.byref(pi)))
+            self.param_table.append(dict(name=pi.name.decode(), kind=pi.kind, R=pi.R, S=pi.S, O=pi.O, I=pi.I, KP=pi.KP,
+                                         offset=pi.offset, numel=pi.numel))
+        self.bn_table = []
+        for i in range(lib.octseg_plan_num_bn(probe.handle)):
+            bi = L.BNInfo()
+            L.check(lib.octseg_plan_bn_info(probe.handle, i, C.byref(bi)))
+            self.bn_table.append(dict(name=bi.name.decode(), C=bi.C, mean_offset=bi.mean_offset, var_offset=bi.var_offset))
+        self.param_numel = lib.octseg_plan_param_numel(probe.handle)
+        self.buffer_numel = lib.octseg_plan_buffer_numel(probe.handle)
+        del probe
+        self.arena = nn.Parameter(torch.zeros(self.param_numel, dtype=torch.float32, device=self.device))
+        self.register_buffer('bn_buffers', torch.zeros(self.buffer_numel, dtype=torch.float32, device=self.device))
+        self.register_buffer('num_batches_tracked', torch.zeros((), dtype=torch.long))
+        self._grad_arena = torch.zeros(self.param_numel, dtype=torch.float32, device=self.device)
+        self._by_name = {p['name']: p for p in self.param_table}
+        self.initialize(seed)
+
+    # ------------------------------------------------------------------ parameter views
+    def _torch_view(self, p, arena=None):
+        """View of one parameter in torch's layout (no copy)."""
+        arena = self.arena.data if arena is None else arena
+        flat = arena[p['offset']:p['offset'] + p['numel']]
+        if p['kind'] == L.P_CONV:
+            return flat.view(p['R'], p['S'], p['O'], p['I']).permute(2, 3, 0, 1)
+        if p['kind'] == L.P_CONVT:
+            return flat.view(p['R'], p['S'], p['O'], p['I']).permute(3, 2, 0, 1)
+        if p['kind'] == L.P_STEM:
+            return flat.view(p['O'], p['KP'])[:, :147].view(p['O'], 7, 7, 3).permute(0, 3, 1, 2)
+        return flat
+
+    def torch_shape(self, p):
+        return tuple(self._torch_view(p).shape)
+
+    def initialize(self, seed=None):
+        """smp/torchvision initialisers: encoder kaiming_normal(fan_out), decoder
+        kaiming_uniform(fan_in), ConvTranspose2d torch default, head xavier_uniform, BN 1/0."""
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        with torch.no_grad():
+            self.arena.zero_()
+            for p in self.param_table:
+                shape = self.torch_shape(p)
+                name = p['name']
+                t = torch.empty(shape)
+                if p['kind'] == L.P_VEC:
+                    if name.endswith('.bias'):
+                        t.zero_()
+                        if p['name'].endswith('.1.0.bias') and '.block.' in name:  # ConvTranspose2d bias default
+                            fan_in = self._by_name[name[:-4] + 'weight']['O'] * 16
+                            bound = 1.0 / fan_in ** 0.5
+                            t.uniform_(-bound, bound, generator=g)
+                    else:
+                        t.fill_(1.0)
+                elif name.startswith('encoder.'):
+                    nn.init.kaiming_normal_(t, mode='fan_out', nonlinearity='relu', generator=g)
+                elif name.startswith('segmentation_head.'):
+                    nn.init.xavier_uniform_(t, generator=g)
+                elif p['kind'] == L.P_CONVT:
+                    nn.init.kaiming_uniform_(t, a=5 ** 0.5, generator=g)
+                else:
+                    nn.init.kaiming_uniform_(t, mode='fan_in', nonlinearity='relu', generator=g)
+                self._torch_view(p).copy_(t.to(self.device))
+            for b in self.bn_table:
+                self.bn_buffers[b['mean_offset']:b['mean_offset'] + b['C']] = 0.0
+                self.bn_buffers[b['var_offset']:b['var_offset'] + b['C']] = 1.0
+            self.num_batches_tracked.zero_()
+
+    # ------------------------------------------------------------------ state_dict in reference key space
+    def state_dict(self, destination=None, prefix='', keep_vars=False):
+        sd = OrderedDict() if destination is None else destination
+        bn_by_name = {b['name']: b for b in self.bn_table}
+        for p in self.param_table:
+            sd[prefix + p['name']] = self._torch_view(p).detach().clone().contiguous()
+            if p['name'].endswith('.bias') and p['name'][:-5] in bn_by_name:
+                b = bn_by_name[p['name'][:-5]]
+                base = prefix + b['name']
+                sd[base + '.running_mean'] = self.bn_buffers[b['mean_offset']:b['mean_offset'] + b['C']].clone()
+                sd[base + '.running_var'] = self.bn_buffers[b['var_offset']:b['var_offset'] + b['C']].clone()
+                sd[base + '.num_batches_tracked'] = self.num_batches_tracked.clone()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        expected = set(self.state_dict().keys())
+        missing = sorted(expected - set(state_dict))
+        unexpected = sorted(set(state_dict) - expected)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'Error(s) in loading state_dict for SegNet: missing keys {missing[:5]}..., '
+                               f'unexpected keys {unexpected[:5]}...')
+        with torch.no_grad():
+            for p in self.param_table:
+                if p['name'] in state_dict:
+                    src = state_dict[p['name']]
+                    view = self._torch_view(p)
+                    if tuple(src.shape) != tuple(view.shape):
+                        raise RuntimeError(f"size mismatch for {p['name']}: {tuple(src.shape)} vs {tuple(view.shape)}")
+                    view.copy_(src.to(self.device, torch.float32))
+            for b in self.bn_table:
+                for key, off in (('running_mean', b['mean_offset']), ('running_var', b['var_offset'])):
+                    k = f"{b['name']}.{key}"
+                    if k in state_dict:
+                        self.bn_buffers[off:off + b['C']] = state_dict[k].to(self.device, torch.float32)
+                k = f"{b['name']}.num_batches_tracked"
+                if k in state_dict:
+                    self.num_batches_tracked.copy_(state_dict[k])
+        return nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def named_grads(self):
+        """Gradients of the last backward, per parameter, in torch layout (for parity tests)."""
+        src = self.arena.grad if self.arena.grad is not None else self._grad_arena
+        return OrderedDict((p['name'], self._torch_view(p, src).detach().clone().contiguous()) for p in self.param_table)
+
+    # ------------------------------------------------------------------ execution
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = _Plan(self.arch, self.encoder_name, self.classes, B, H, W, self.dtype_code)
+        return self._plans[key]
+
+    def fwd_macs(self, B, H, W):
+        return L.lib().octseg_plan_fwd_macs(self._plan(B, H, W).handle)
+
+    def _check_input(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            raise ValueError(f'expected a float32 CUDA tensor [B,3,H,W], got {tuple(x.shape)} {x.dtype} {x.device}')
+        return x.contiguous()
+
+    def _run_forward(self, x, normalize, mean, std, train):
+        x = self._check_input(x)
+        B, _, H, W = x.shape
+        plan = self._plan(B, H, W)
+        logits = torch.empty((B, self.classes, H, W), dtype=torch.float32, device=x.device)
+        m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
+        s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
+        L.check(L.lib().octseg_net_forward(plan.handle, L.ptr(self.arena.data), L.ptr(self.bn_buffers), L.ptr(plan.ws(x.device)),
+                                           L.ptr(x), L.ptr(logits), int(bool(normalize)), m, s, int(bool(train)),
+                                           L.stream_ptr()))
+        if train:
+            self.num_batches_tracked += 1
+        return logits, plan
+
+    def forward(self, x, normalize=False, mean=None, std=None):
+        logits, _ = self._run_forward(x, normalize, mean, std, self.training)
+        return logits
+
+    def dice(self, plan, logits, target):
+        target = target.contiguous()
+        if tuple(target.shape) != tuple(logits.shape) or target.dtype != torch.float32:
+            raise ValueError(f'mask must be float32 {tuple(logits.shape)}, got {target.dtype} {tuple(target.shape)}')
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        stats = torch.empty((logits.shape[0], self.classes, 4), dtype=torch.int64, device=logits.device)
+        L.check(L.lib().octseg_dice_forward(plan.handle, L.ptr(plan.ws(logits.device)), L.ptr(logits), L.ptr(target),
+                                            L.ptr(loss), L.ptr(stats), L.stream_ptr()))
+        return loss, stats
+
+    def _forward_loss(self, image, target, normalize, mean, std):
+        logits, plan = self._run_forward(image, normalize, mean, std, self.training)
+        loss, stats = self.dice(plan, logits, target)
+        return logits, loss, stats, plan
+
+    def _backward(self, plan, logits, target, grad_scale=1.0):
+        L.check(L.lib().octseg_net_backward(plan.handle, L.ptr(self.arena.data), L.ptr(self._grad_arena),
+                                            L.ptr(plan.ws(logits.device)), L.ptr(logits), L.ptr(target.contiguous()),
+                                            float(grad_scale), L.stream_ptr()))
+        return self._grad_arena
+
+    def dice_step(self, image, target, normalize=False, mean=None, std=None):
+        """Forward + Dice loss.  Returns (loss, logits, stats[B,C,4]); ``loss.backward()`` runs the
+        HIP backward and accumulates into ``self.arena.grad``."""
+        if torch.is_grad_enabled() and self.training:
+            return _DiceStep.apply(self.arena, self, image, target, normalize, mean, std)
+        logits, loss, stats, _ = self._forward_loss(image, target, normalize, mean, std)
+        return loss, logits, stats
+
+    def train_step_raw(self, image, target, normalize=False, mean=None, std=None, grad_scale=1.0):
+        """Forward + Dice + backward without autograd: gradients land in ``grad_arena`` (and are
+        exposed as ``arena.grad`` without a copy).  The bench / DP loop uses this."""
+        logits, loss, stats, plan = self._forward_loss(image, target, normalize, mean, std)
+        self._backward(plan, logits, target, grad_scale)
+        self.arena.grad = self._grad_arena
+        return loss, logits, stats
+
+
+def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):
+    """Drop-in for ``smp.create_model`` on the hot-path architectures."""
+    return SegNet(arch, encoder_name, encoder_weights=encoder_weights, in_channels=in_channels, classes=classes, **kwargs)
+
+
+def debug_tensor(net, plan, conv_name, grad=False):
+    """Test hook: copy of a conv layer's raw output (or of its gradient buffer) as NCHW float32."""
+    act, gr = C.c_size_t(), C.c_size_t()
+    dims = (C.c_int * 4)()
+    L.check(L.lib().octseg_plan_find_tensor(plan.handle, conv_name.encode(), C.byref(act), C.byref(gr), dims))
+    N, H, W, Cc = list(dims)
+    esz = 4 if net.dtype_code == L.F32 else 2
+    off = gr.value if grad else act.value
+    raw = plan.workspace[off:off + N * H * W * Cc * esz]
+    t = raw.view(torch.float32 if esz == 4 else torch.bfloat16).view(N, H, W, Cc)
+    return t.float().permute(0, 3, 1, 2).contiguous()

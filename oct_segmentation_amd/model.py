@@ -1,0 +1,176 @@
+"""``OCTSegmentationModel`` -- host-side mirror of the reference task module
+(``src/models/smp/model.py:18-200``) over the gfx950 engine.
+
+Same constructor keywords, same methods (``forward``, ``training_step``,
+``validation_step``, ``configure_optimizers``, ``predict``,
+``load_from_checkpoint``), same ``state_dict`` keys (``model.*``, ``mean``,
+``std``).  Lightning, W&B, cv2 and the per-epoch image dump are not part of the
+hot path and are not reproduced (out of scope).
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import SegNet, get_preprocessing_params
+from .metrics import get_metrics_from_stats
+
+# reference src/data/utils.py:16-45
+CLASS_IDS = {'Lumen': 1, 'Fibrous cap': 2, 'Lipid core': 3, 'Vasa vasorum': 4}
+
+
+class DiceLoss:
+    """Marker object kept for API parity (``self.loss_fn``); the loss itself is fused into the
+    engine (``SegNet.dice_step``): smp DiceLoss(MULTILABEL_MODE, from_logits=True), model.py:55."""
+    mode = 'multilabel'
+    from_logits = True
+    smooth = 0.0
+    eps = 1e-7
+
+
+class FusedOptimizer:
+    """torch.optim-like wrapper of ``octseg_optim_step`` over the flat parameter arena
+    (SGD | Adam | RMSprop | RAdam with torch defaults, coupled L2 weight decay; model.py:150-181)."""
+
+    def __init__(self, net, name, lr, weight_decay):
+        if name not in L.OPT_KINDS:
+            raise ValueError(f'Unknown optimizer: {name}')
+        self.net, self.name, self.kind = net, name, L.OPT_KINDS[name]
+        self.lr, self.weight_decay = float(lr), float(weight_decay)
+        self.step_count = 0
+        n, dev = net.param_numel, net.device
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if self.kind in (1, 3) else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev) if self.kind in (1, 2, 3) else None
+        self.param_groups = [{'params': [net.arena], 'lr': self.lr, 'weight_decay': self.weight_decay}]
+
+    def zero_grad(self, set_to_none=True):
+        self.net.arena.grad = None
+
+    def step(self, grad_scale=1.0):
+        g = self.net.arena.grad
+        if g is None:
+            raise RuntimeError('optimizer.step() called before any backward')
+        self.step_count += 1
+        self.lr = float(self.param_groups[0]['lr'])
+        L.check(L.lib().octseg_optim_step(self.kind, L.ptr(self.net.arena.data), L.ptr(g), L.ptr(self.m), L.ptr(self.v),
+                                          self.net.param_numel, self.lr, self.weight_decay, self.step_count,
+                                          float(grad_scale), L.stream_ptr()))
+
+    def state_dict(self):
+        return {'name': self.name, 'step': self.step_count, 'lr': self.lr, 'weight_decay': self.weight_decay,
+                'm': self.m, 'v': self.v}
+
+
+class OCTSegmentationModel(nn.Module):
+    """The model dedicated to the segmentation of OCT images (MI355X engine)."""
+
+    def __init__(self, arch, encoder_name, model_name, in_channels, classes, lr=0.0001, data_dir=None,
+                 weight_decay=0.0001, optimizer_name='Adam', input_size=512, img_save_interval=1,
+                 save_wandb_media=False, device='cuda', compute_dtype=torch.bfloat16, fused_optimizer=True, **kwargs):
+        super().__init__()
+        self.model = SegNet(arch, encoder_name, in_channels=in_channels, classes=len(classes), device=device,
+                            compute_dtype=compute_dtype, **kwargs)
+        self.classes = list(classes)
+        self.data_dir = data_dir
+        self.epoch = 0
+        params = get_preprocessing_params(encoder_name)
+        dev = self.model.device
+        self.register_buffer('std', torch.tensor(params['std'], device=dev).view(1, 3, 1, 1))
+        self.register_buffer('mean', torch.tensor(params['mean'], device=dev).view(1, 3, 1, 1))
+        self._mean, self._std = list(params['mean']), list(params['std'])
+        self.training_step_outputs = []
+        self.validation_step_outputs = []
+        self.validation_best_metrics = {}
+        self.loss_fn = DiceLoss()
+        self.model_name = model_name
+        self.lr, self.weight_decay, self.optimizer = lr, weight_decay, optimizer_name
+        self.input_size = input_size
+        self.img_save_interval, self.save_wandb_media = img_save_interval, save_wandb_media
+        self.fused_optimizer = fused_optimizer
+        self.class_values = [CLASS_IDS[cl] for cl in self.classes if cl in CLASS_IDS]
+
+    # ---- model.py:65-71: (image - mean) / std is fused into the stem's im2col load
+    def forward(self, image):
+        return self.model(image, normalize=True, mean=self._mean, std=self._std)
+
+    def _step(self, batch):
+        img, mask = batch
+        loss, logits, stats = self.model.dice_step(img, mask, normalize=True, mean=self._mean, std=self._std)
+        return loss, logits, stats
+
+    # ---- model.py:73-95.  The thresholded mask and tp/fp/fn/tn come out of the Dice kernel.
+    def training_step(self, batch, batch_idx=0):
+        loss, logits, stats = self._step(batch)
+        self.training_step_outputs.append(get_metrics_from_stats(stats, loss))
+        return {'loss': loss}
+
+    # ---- model.py:108-132
+    def validation_step(self, batch, batch_idx=0):
+        with torch.no_grad():
+            loss, logits, stats = self._step(batch)
+        self.validation_step_outputs.append(get_metrics_from_stats(stats, loss))
+        return {'val/loss': loss, 'val/f1': float(np.mean(self.validation_step_outputs[-1]['f1']).mean())}
+
+    # ---- model.py:150-181
+    def configure_optimizers(self):
+        if self.optimizer not in ('SGD', 'RMSprop', 'RAdam', 'SAdam', 'Adam'):
+            raise ValueError(f'Unknown optimizer: {self.optimizer}')
+        if self.optimizer == 'SAdam':  # torch.optim.SparseAdam raises on dense grads in the reference too
+            raise ValueError('SAdam (SparseAdam) cannot optimise dense gradients')
+        if self.fused_optimizer:
+            return FusedOptimizer(self.model, self.optimizer, self.lr, self.weight_decay)
+        cls = {'SGD': torch.optim.SGD, 'RMSprop': torch.optim.RMSprop, 'RAdam': torch.optim.RAdam,
+               'Adam': torch.optim.Adam}[self.optimizer]
+        return cls(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+
+    # ---- model.py:183-200: NHWC numpy in, no normalisation, sigmoid > 0.5, NHWC numpy out
+    def predict(self, images, device='cuda'):
+        x = torch.Tensor(images.transpose((0, 3, 1, 2))).to(self.model.device)
+        was_training = self.model.training
+        try:
+            y = self.model(x, normalize=False)
+        finally:
+            self.model.train(was_training)
+        masks = (y.sigmoid() > 0.5).float().cpu()
+        return masks.permute(0, 2, 3, 1).numpy().round()
+
+    @staticmethod
+    def to_tensor_shape(x):
+        return x.transpose([2, 0, 1]).astype('float32')
+
+    # ---- checkpoint compatibility (predict.py:39-48): Lightning .ckpt = pickled dict with 'state_dict'
+    def state_dict(self, *args, **kwargs):
+        sd = self.model.state_dict(prefix='model.')
+        sd['std'] = self.std.clone()
+        sd['mean'] = self.mean.clone()
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        inner = {k[len('model.'):]: v for k, v in state_dict.items() if k.startswith('model.')}
+        res = self.model.load_state_dict(inner, strict=strict)
+        for k in ('mean', 'std'):
+            if k in state_dict:
+                getattr(self, k).copy_(state_dict[k].to(getattr(self, k).device))
+        self._mean = [float(v) for v in self.mean.flatten().cpu()]
+        self._std = [float(v) for v in self.std.flatten().cpu()]
+        return res
+
+    def save_checkpoint(self, path, epoch=0, global_step=0):
+        ckpt = {'epoch': epoch, 'global_step': global_step, 'pytorch-lightning_version': '2.2.1',
+                'state_dict': {k: v.cpu() for k, v in self.state_dict().items()}}
+        torch.save(ckpt, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+        kwargs.pop('encoder_weights', None)
+        if map_location not in (None, 'cpu'):
+            kwargs.setdefault('device', map_location)
+        try:
+            ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+        except pickle.UnpicklingError as e:  # pragma: no cover
+            raise RuntimeError(f'cannot read checkpoint {checkpoint_path}: {e}')
+        model = cls(**kwargs)
+        model.load_state_dict(ckpt['state_dict'], strict=True)
+        return model
