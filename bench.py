@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- OCT frames/s of the training hot path on MI355X.
+
+One "step" = one optimisation step over a batch of synthetic OCT-shaped 704x704 frames:
+forward (normalise + encoder-decoder) + Dice loss + backward + gradient all-reduce (N > 1)
++ fused Adam step, all inside the timed region, inputs resident in HBM.
+
+Workload (BASELINE.json configs[1]): U-Net++ / resnet101, 1 class (Lumen), 704x704, bf16
+storage + bf16 MFMA inputs with f32 accumulate, batch 16 per GPU.  N > 1: one process per GPU
+(torchrun), data parallel with per-rank BN statistics / per-rank Dice and one RCCL all-reduce of
+the flat gradient arena (Lightning-DDP semantics, reference src/models/smp/train.py:122-133);
+per-GPU batch stays 16, so scaling is "weak".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline      -- the MFMA conv kernels (conv_mfma_kernel + wgrad_mfma_kernel), timed live with HIP
+                   events on the launch stream over the timed steps: algorithmic conv FLOPs
+                   (6 * MACs * frames) / summed kernel time, vs 2.5 PFLOP/s dense bf16
+  cpu_baseline  -- the torch-CPU oracle (a port, not the reference's own files) on one 704x704
+                   frame of the same workload, fp32, all host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (arch, encoder, classes, size)
+    'unetpp_r101_704': ('unetplusplus', 'resnet101', 1, 704),
+    'linknet_r50_704': ('linknet', 'resnet50', 2, 704),
+    'unet_r50_704': ('unet', 'resnet50', 1, 704),
+    'unet_r18_256': ('unet', 'resnet18', 1, 256),
+}
+
+
+def cpu_baseline(arch, enc, classes, size, seconds_hint=30.0):
+    """Oracle fwd + Dice + bwd + Adam on the host cores; bounded sample: ONE frame, fp32."""
+    from oracle import create_model, DiceLoss
+    from synth import make_batch
+    # the GPU box gives one-GPU jobs a 16-core share; os.cpu_count() reports the whole host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = create_model(arch, enc, classes=classes).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+    loss_fn = DiceLoss()
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+
+    def step(img, mask):
+        opt.zero_grad()
+        loss = loss_fn(m((img - mean) / std), mask)
+        loss.backward()
+        opt.step()
+
+    wi, wm = make_batch(1, classes, 64, seed=1)
+    step(wi, wm)  # warm the allocator / oneDNN primitives on a tiny frame
+    img, mask = make_batch(1, classes, size, seed=2)
+    t0 = time.time()
+    step(img, mask)
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 step of 1 frame {size}x{size} fp32 ({arch}/{enc}, fwd+Dice+bwd+Adam), torch {torch.__version__} CPU oracle, '
+                      f'{dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='unetpp_r101_704', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--optimizer', default='Adam')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    from oct_segmentation_amd.parallel import allreduce_gradients, broadcast_buffers, broadcast_parameters
+    from synth import make_batch
+    import ctypes as C
+
+    arch, enc, classes, S = WORKLOADS[args.workload]
+    B = args.batch
+    cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    names = ['Lumen', 'Fibrous cap', 'Lipid core', 'Vasa vasorum'][:classes]
+    model = OCTSegmentationModel(arch, enc, 'bench', 3, names, lr=1e-5, weight_decay=0.0, optimizer_name=args.optimizer,
+                                 input_size=S, device=dev, compute_dtype=cdt, seed=1234)
+    model.train()
+    net = model.model
+    if world > 1:
+        broadcast_parameters(net)
+    opt = model.configure_optimizers()
+    img, mask = make_batch(B, classes, S, seed=1234 + rank)
+    img, mask = img.to(dev), mask.to(dev)
+
+    def step():
+        if world > 1:
+            broadcast_buffers(net)  # torch-DDP broadcast_buffers=True
+        # grad_scale 1/world + SUM all-reduce == DDP's gradient mean
+        loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
+                                                 grad_scale=1.0 / world)
+        if world > 1:
+            allreduce_gradients(net, world, average=False)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+    note(f'{arch}/{enc} {S}x{S} batch {B}/GPU {args.dtype}: warm-up x{args.warmup}')
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    note(f'timing {args.steps} steps')
+    L.check(L.lib().octseg_profile_start())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = (C.c_double * 9)()
+    L.check(L.lib().octseg_profile_stop(prof))
+    loss_val = float(loss.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        macs = net.fwd_macs(B, S, S) / B  # per frame
+        ms = [prof[0], prof[3], prof[6]]
+        fl = [prof[1], prof[4], prof[7]]
+        nl = [prof[2], prof[5], prof[8]]
+        tot_ms, tot_fl = sum(ms), sum(fl)
+        peak = 2500.0 if args.dtype == 'bf16' else 157.3
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        out = {
+            'metric': 'OCT frames/sec (704x704, bf16) fwd+bwd',
+            'value': round(frames / dt, 3),
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic OCT-shaped frames (seeded), random-init weights',
+            'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+Dice+bwd+allreduce+{args.optimizer}',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
+            'loss': round(loss_val, 6),
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                'launches_per_step': round(sum(nl) / args.steps, 1),
+                'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
+                'kernel_ms_per_step': round(tot_ms / args.steps, 3),
+                'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
+                             for k, m, f in zip(('fwd', 'dgrad', 'wgrad'), ms, fl)},
+                'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
+            },
+        }
+        note(f'GPU: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; MFMA kernels {ach:.1f} TFLOP/s')
+        if not args.no_cpu_baseline and world == 1:
+            note('CPU baseline (oracle, 1 frame) ...')
+            out['cpu_baseline'] = cpu_baseline(arch, enc, classes, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

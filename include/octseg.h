@@ -93,6 +93,13 @@ double octseg_plan_fwd_macs(const octseg_plan* plan);      /* conv multiply-accu
 int octseg_plan_find_tensor(const octseg_plan* plan, const char* conv_name, size_t* act_off,
                             size_t* grad_off, int* dims);
 
+/* Measurement hooks (bench.py): between _start and _stop every MFMA conv launch is bracketed by HIP
+ * events on its launch stream.  _stop synchronises the device and fills out[9]:
+ * out[3k+0..2] = {milliseconds, algorithmic FLOPs, launches} for k = 0 conv forward, 1 conv
+ * data-gradient, 2 weight gradient. */
+int octseg_profile_start(void);
+int octseg_profile_stop(double* out);
+
 /* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
  * train=1: batch statistics, running buffers updated, activations kept for backward. */
 int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,

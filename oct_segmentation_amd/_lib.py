@@ -6,6 +6,10 @@ fails, a ``RuntimeError`` is raised with ``octseg_last_error()``.
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64; it must be the HIP runtime this process binds (streams and device
+# pointers are torch's), so torch is loaded before liboctseg_hip.so resolves its libamdhip64 dependency.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liboctseg_hip.so')
 
@@ -44,6 +48,8 @@ SYMBOLS = {
     'octseg_plan_bn_info': (C.c_int, [_P, C.c_int, C.POINTER(BNInfo)]),
     'octseg_plan_fwd_macs': (C.c_double, [_P]),
     'octseg_plan_find_tensor': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'octseg_profile_start': (C.c_int, []),
+    'octseg_profile_stop': (C.c_int, [C.POINTER(C.c_double)]),
     'octseg_net_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_int, _P]),
     'octseg_dice_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),

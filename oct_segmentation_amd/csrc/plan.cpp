@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <vector>
 
 using namespace octseg;
 
@@ -27,6 +28,36 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- in-process kernel timing
+// bench.py brackets every MFMA launch with HIP events on the launch stream (octseg_profile_start /
+// _stop); classes: 0 conv forward, 1 conv data-gradient, 2 weight gradient.
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+struct ProfScope {
+  hipStream_t st; ProfRec r; bool on;
+  ProfScope(int kind, double flops, hipStream_t s) : st(s), on(g_prof_on) {
+    if (!on) return;
+    r.kind = kind; r.flops = flops; r.a = prof_event(); r.b = prof_event();
+    if (!r.a || !r.b) { on = false; return; }
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    g_prof.push_back(r);
+  }
+};
+}  // namespace
 
 // ================================================================ tap tables / launch geometry
 static void set_taps(signed char* tdy, signed char* tdx, unsigned char* tw, int n, int& ntaps, int& min_dy,
@@ -452,6 +483,11 @@ struct Exec {
 
 }  // namespace
 
+// algorithmic multiply-accumulates of one pass (forward = dgrad = wgrad) over a conv layer
+static double layer_macs(const ConvLayer& L) {
+  return (double)L.N * L.OH * L.OW * L.Cout * (L.stem ? 147.0 : (double)L.Cin * (L.transposed ? 4.0 : (double)L.R * L.S));
+}
+
 static int pack_all_weights(Exec& E) {
   octseg_plan* P = E.P;
   for (auto& L : P->convs) {
@@ -499,6 +535,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.stat_slab = (L.bn >= 0 && E.train) ? (float*)(E.ws + P->slab_off) : nullptr;
           a.slab_row0 = row0;
           row0 += conv_num_mtiles(a);
+          ProfScope ps(0, 2.0 * layer_macs(L) / (double)la.size(), E.st);
           HIPCHK(launch_conv(P->dtype, a, E.st));
         }
         break;
@@ -583,6 +620,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.nsrc = E.fill_srcs(L, a.src);
       a.dy = dy; a.dyC = dyC;
       a.dW = E.grads + P->params[L.w].off;
+      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), E.st);
       HIPCHK(launch_wgrad(P->dtype, a, E.st));
     }
   }
@@ -620,6 +658,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     a.ndst = nd;
     a.out_mode = OUT_ACCUM;
     a.bias = nullptr; a.stat_slab = nullptr;
+    ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st);
     HIPCHK(launch_conv(P->dtype, a, E.st));
   }
   if (up_src >= 0) {
@@ -739,6 +778,29 @@ int octseg_plan_bn_info(const octseg_plan* p, int i, octseg_bn_info* o) {
   memset(o, 0, sizeof(*o));
   snprintf(o->name, sizeof o->name, "%s", b.name.c_str());
   o->C = b.C; o->mean_offset = b.rm_off; o->var_offset = b.rv_off;
+  return OCTSEG_OK;
+}
+
+int octseg_profile_start(void) {
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+  return OCTSEG_OK;
+}
+// out[3*k + {0,1,2}] = {milliseconds, algorithmic FLOPs, launches} of class k = 0 fwd, 1 dgrad, 2 wgrad.
+// Synchronises the device (bench / test use only).
+int octseg_profile_stop(double* out) {
+  g_prof_on = false;
+  if (!out) return fail(OCTSEG_BAD_ARG, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  for (int i = 0; i < 9; ++i) out[i] = 0.0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    out[3 * r.kind] += ms; out[3 * r.kind + 1] += r.flops; out[3 * r.kind + 2] += 1.0;
+  }
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+  g_prof.clear();
   return OCTSEG_OK;
 }
 
