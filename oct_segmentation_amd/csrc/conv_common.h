@@ -135,4 +135,56 @@ static __device__ __forceinline__ void stage_window(char* lds, const SrcDesc* sr
 }
 
 
+// Pass-wise stager of the input window: pass p covers window pixels [p*PSTEP, (p+1)*PSTEP), one
+// 16-byte channel vector per thread.  load() only issues the global load, write() applies the lazy
+// BN/ReLU and stores to LDS -- the caller puts MFMAs in between so the HBM/L2 latency is hidden.
+template <typename T, int RB, int NT_>
+struct WindowStager {
+  static constexpr int VEC = Tr<T>::VEC;
+  static constexpr int KC = RB / (int)sizeof(T);
+  static constexpr int VPR = RB / 16;
+  static constexpr int PSTEP = NT_ / VPR;
+  static constexpr int PITCH = RB + 16;
+  SrcSel s;
+  float sc[VEC], sh[VEC];
+  bool cvalid, has_aff;
+  int cv, p0;
+  __device__ __forceinline__ void setup(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid) {
+    cv = tid % VPR;
+    p0 = tid / VPR;
+    const int c = chunk * KC + cv * VEC;
+    cvalid = c < Cin;
+    s = select_src(src, nsrc, cvalid ? c : 0);
+    has_aff = cvalid && s.scale != nullptr;
+    if (has_aff) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { sc[i] = s.scale[s.cl + i]; sh[i] = s.shift[s.cl + i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+    }
+  }
+  __device__ __forceinline__ uint4 load(int pass, int n, int gy0, int gx0, int smul, int RW, int npix, float inv_rw,
+                                        int IH, int IW, bool& ok) const {
+    const int hp = pass * PSTEP + p0;
+    const int hy = (int)(((float)hp + 0.5f) * inv_rw);
+    const int hx = hp - hy * RW;
+    const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
+    ok = cvalid && hp < npix && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) {
+      const size_t e = (((size_t)n * s.H + (iy >> s.up)) * s.W + (ix >> s.up)) * s.C + s.cl;
+      v = *(const uint4*)(s.ptr + e * sizeof(T));
+    }
+    return v;
+  }
+  __device__ __forceinline__ void write(char* lds, int pass, int npix, uint4 v, bool ok) const {
+    const int hp = pass * PSTEP + p0;
+    if (hp < npix) {
+      if (ok && has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
+      *(uint4*)(lds + hp * PITCH + cv * 16) = v;
+    }
+  }
+};
+
 }  // namespace octseg

@@ -9,35 +9,43 @@
 // nearest-x2 upsampled and lazily batch-normalised (relu(x*scale+shift)) while it
 // is staged into LDS -- torch.cat / F.interpolate / BN-apply / ReLU never touch HBM.
 //
-// Tiling: a workgroup (4 waves) owns an 8x16 tile of output pixels x BN output
-// channels.  Per 128-byte channel chunk the (8+halo)x(16+halo) input window is
-// staged once into LDS; every tap then reads its A fragments from the same window
-// at a shifted LDS address (no im2col buffer anywhere).  Weights stream per tap
-// through a double-buffered LDS slab.  Wave tile 64 px x BN/2 channels built from
-// 32x32 MFMA tiles: v_mfma_f32_32x32x16_bf16 (bf16) or 4x v_mfma_f32_32x32x2_f32
-// (exact f32 fmaf chain, used by the 1e-4 parity path).
-// The epilogue adds bias, emits per-channel (sum, sumsq) partials for the following
-// BatchNorm (deterministic slab, reduced by bn_finalize), and stores / accumulates.
+// Tiling: a workgroup of WM x WN waves owns a (4*WM) x 16 tile of output pixels x BN output
+// channels; every wave computes 64 pixels x NT*32 channels from 32x32 MFMA tiles
+// (v_mfma_f32_32x32x16_bf16, or 4x v_mfma_f32_32x32x2_f32 = exact f32 fmaf chain for the parity
+// path).  Per channel chunk (RB bytes of K) the (tile + halo) input window is staged ONCE into LDS
+// and every tap reads its A fragments from it at a shifted address (no im2col buffer anywhere);
+// weights stream per tap through a double-buffered LDS slab.  Software pipeline: while the MFMAs of
+// (chunk c, tap t) run, the global loads of the next weight slab and of a slice of chunk c+1's
+// window are in flight (register staged, written to the other LDS buffers after the MFMAs), one
+// barrier per tap.  The epilogue adds bias, emits per-channel (sum, sumsq) partials for the
+// following BatchNorm (deterministic slab, reduced by bn_finalize), transposes the accumulators
+// through LDS and stores / accumulates whole 16-byte channel vectors.
 #include "common.h"
 #include "conv_common.h"
 #include "kernels.h"
 
 namespace octseg {
 
-constexpr int TH = 8;                 // output-grid tile height
-constexpr int ROWB = 128;             // channel-chunk bytes per LDS row
-constexpr int PITCH = ROWB + 16;      // padded row pitch (bank spread for ds_read_b128)
+template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS = RB / 32, VPR = RB / 16; };
 
-template <typename T, int BN>
-__global__ __launch_bounds__(NTHR) void conv_mfma_kernel(const ConvArgs a) {
+template <typename T, int NT, int WN, int WM, int RB>
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a, const int dbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHREADS = 64 * WM * WN;
+  constexpr int BN = NT * 32 * WN;
+  constexpr int TH = 4 * WM;
+  constexpr int BM = TH * TW;
   constexpr int VEC = Tr<T>::VEC;
-  constexpr int KC = ROWB / (int)sizeof(T);
-  constexpr int NT = BN / 64;            // 32-wide n tiles per wave
-  constexpr int BROWS_PER_THR = BN * 8 / NTHR;
+  constexpr int KC = RB / (int)sizeof(T);
+  constexpr int PITCH = ConvCfg<RB>::PITCH, KSTEPS = ConvCfg<RB>::KSTEPS, VPR = ConvCfg<RB>::VPR;
+  constexpr int BVEC = BN * VPR;                              // 16-byte vectors of one weight slab
+  constexpr int BPT = (BVEC + NTHREADS - 1) / NTHREADS;       // per thread
+  constexpr int BBYTES = BN * PITCH;
+  constexpr int MAXP = 4;                                     // window passes prefetched per tap
+  typedef WindowStager<T, RB, NTHREADS> Stager;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
   const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
@@ -55,12 +63,14 @@ __global__ __launch_bounds__(NTHR) void conv_mfma_kernel(const ConvArgs a) {
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
+  const int npass = (npix + Stager::PSTEP - 1) / Stager::PSTEP;
+  const int ppt = (npass + a.ntaps - 1) / a.ntaps;            // passes prefetched per tap (<= MAXP by host check)
   const float inv_rw = 1.0f / (float)RW;
   const int gy0 = y0 * a.istride + a.min_dy, gx0 = x0 * a.istride + a.min_dx;
 
-  char* ldsA = smem;
-  char* ldsB = smem + ((npix * PITCH + 15) & ~15);
-  constexpr int BBYTES = BN * PITCH;
+  const int abytes = (npix * PITCH + 15) & ~15;
+  char* ldsA = smem;                                  // [1 or 2] windows
+  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slabs
 
   f32x16_t acc[2][NT];
 #pragma unroll
@@ -77,51 +87,85 @@ __global__ __launch_bounds__(NTHR) void conv_mfma_kernel(const ConvArgs a) {
     abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * (BN / 2) + nt * 32 + r) * PITCH + h * 16;
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * NT * 32 + nt * 32 + r) * PITCH + h * 16;
 
   const int nchunks = (a.Cin + KC - 1) / KC;
   const char* Wp = (const char*)a.W;
 
-  // weight slab loader: rows = output channels, 8 vectors of 16 B per row
   auto loadB = [&](int tapw, int chunk, uint4* regs) {
 #pragma unroll
-    for (int i = 0; i < BROWS_PER_THR; ++i) {
-      const int v = tid + i * NTHR;
-      const int row = v >> 3, cv = v & 7;
+    for (int i = 0; i < BPT; ++i) {
+      const int v = tid + i * NTHREADS;
+      const int row = v / VPR, cv = v % VPR;
       const int co = co0 + row, c = chunk * KC + cv * VEC;
       regs[i] = make_uint4(0, 0, 0, 0);
-      if (co < a.Cout && c < a.Cin)
+      if (v < BVEC && co < a.Cout && c < a.Cin)
         regs[i] = *(const uint4*)(Wp + (((size_t)tapw * a.Cout + co) * a.Cin + c) * sizeof(T));
     }
   };
   auto writeB = [&](char* dstb, const uint4* regs) {
 #pragma unroll
-    for (int i = 0; i < BROWS_PER_THR; ++i) {
-      const int v = tid + i * NTHR;
-      *(uint4*)(dstb + (v >> 3) * PITCH + (v & 7) * 16) = regs[i];
+    for (int i = 0; i < BPT; ++i) {
+      const int v = tid + i * NTHREADS;
+      if (v < BVEC) *(uint4*)(dstb + (v / VPR) * PITCH + (v % VPR) * 16) = regs[i];
+    }
+  };
+  auto stage_full = [&](const Stager& sg, char* dst) {
+    for (int p = 0; p < npass; p += MAXP) {
+      uint4 v[MAXP];
+      bool ok[MAXP];
+#pragma unroll
+      for (int u = 0; u < MAXP; ++u) v[u] = sg.load(p + u, n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, ok[u]);
+#pragma unroll
+      for (int u = 0; u < MAXP; ++u) sg.write(dst, p + u, npix, v[u], ok[u]);
     }
   };
 
+  // ---------------- prologue: window of chunk 0 + first weight slab ----------------
+  Stager cur;
+  cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
+  stage_full(cur, ldsA);
+  {
+    uint4 regs[BPT];
+    loadB(a.tap_w[0], 0, regs);
+    writeB(ldsB, regs);
+  }
+  __syncthreads();
+
+  int it = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();  // every wave is done with the previous window / weight slabs
-    stage_window<T, ROWB>(ldsA, a.src, a.nsrc, a.Cin, chunk, n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, tid);
-    {
-      uint4 regs[BROWS_PER_THR];
-      loadB(a.tap_w[0], chunk, regs);
-      writeB(ldsB, regs);
-    }
-    __syncthreads();
-    for (int t = 0; t < a.ntaps; ++t) {
-      uint4 nregs[BROWS_PER_THR];
-      const bool more = t + 1 < a.ntaps;
-      if (more) loadB(a.tap_w[t + 1], chunk, nregs);  // global loads fly under the MFMAs below
-      const int toff = single ? 0 : ((a.tap_dy[t] - a.min_dy) * RW + (a.tap_dx[t] - a.min_dx)) * PITCH;
-      const char* bsl = ldsB + (t & 1) * BBYTES;
+    const bool has_next = chunk + 1 < nchunks;
+    Stager nxt;
+    if (has_next) nxt.setup(a.src, a.nsrc, a.Cin, chunk + 1, tid);
+    const char* awin = ldsA + ((dbuf && (chunk & 1)) ? abytes : 0);
+    char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
+    for (int t = 0; t < a.ntaps; ++t, ++it) {
+      // ---- issue the global loads that will be consumed one iteration / one chunk later ----
+      uint4 nregs[BPT];
+      const bool more_b = (t + 1 < a.ntaps) || has_next;
+      if (more_b) {
+        if (t + 1 < a.ntaps) loadB(a.tap_w[t + 1], chunk, nregs);
+        else loadB(a.tap_w[0], chunk + 1, nregs);
+      }
+      uint4 av[MAXP];
+      bool aok[MAXP];
+      const bool pre_a = dbuf && has_next;
+      if (pre_a) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+        for (int u = 0; u < MAXP; ++u) {
+          aok[u] = false;
+          av[u] = make_uint4(0, 0, 0, 0);
+          if (u < ppt) av[u] = nxt.load(t * ppt + u, n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, aok[u]);
+        }
+      }
+      // ---- MFMAs of (chunk, tap t) ----
+      const int toff = single ? 0 : ((a.tap_dy[t] - a.min_dy) * RW + (a.tap_dx[t] - a.min_dx)) * PITCH;
+      const char* bsl = ldsB + (it & 1) * BBYTES;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
         uint4 af[2], bf[NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[mt] = *(const uint4*)(ldsA + abase[mt] + toff + ks * 32);
+        for (int mt = 0; mt < 2; ++mt) af[mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const uint4*)(bsl + bbase[nt] + ks * 32);
 #pragma unroll
@@ -129,108 +173,225 @@ __global__ __launch_bounds__(NTHR) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[mt], bf[nt], acc[mt][nt]);
       }
-      if (more) writeB(ldsB + ((t + 1) & 1) * BBYTES, nregs);
+      // ---- land the prefetched data in the other LDS buffers ----
+      if (more_b) writeB(ldsB + ((it + 1) & 1) * BBYTES, nregs);
+      if (pre_a) {
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u)
+          if (u < ppt) nxt.write(anext, t * ppt + u, npix, av[u], aok[u]);
+      }
+      __syncthreads();
+    }
+    if (!dbuf && has_next) {  // window does not fit twice: restage in place (all waves passed the barrier)
+      stage_full(nxt, ldsA);
       __syncthreads();
     }
   }
 
   // ---------------- epilogue ----------------
+  // (all waves are past the last barrier: LDS is free)
+  constexpr int OPITCH = BN * (int)sizeof(T) + 16;       // transposed-tile row pitch
+  constexpr int OVPR = BN * (int)sizeof(T) / 16;         // 16-byte vectors per pixel row
+  char* otile = smem;                                    // [BM][BN] T
+  float* red = (float*)(smem + BM * OPITCH);             // [WM][BN][2] stat partials
+  const bool head = a.out_mode == OUT_HEAD_NCHW;
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     s1[nt] = 0.f; s2[nt] = 0.f;
-    const int co = co0 + wn * (BN / 2) + nt * 32 + r;
+    const int cl = wn * NT * 32 + nt * 32 + r;
+    const int co = co0 + cl;
     const bool cok = co < a.Cout;
-    // destination slice of this channel
-    char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W;
-#pragma unroll
-    for (int i = 1; i < MAX_SRC; ++i)
-      if (i < a.ndst && co >= a.dst[i].c0) {
-        dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W;
-      }
     const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int p = mt * 32 + rr;
-        const int gy = y0 + wm * 4 + (p >> 4), gx = x0 + (p & 15);
+        const int p = mt * 32 + rr;                       // pixel inside the wave's 64
+        const int ty = wm * 4 + (p >> 4), tx = p & 15;
+        const int gy = y0 + ty, gx = x0 + tx;
+        const float val = acc[mt][nt][i] + bias;
         if (cok && gy < a.OH && gx < a.OW) {
-          const float val = acc[mt][nt][i] + bias;
           s1[nt] += val; s2[nt] += val * val;
-          const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
-          if (a.out_mode == OUT_HEAD_NCHW) {
-            ((float*)dptr)[(((size_t)n * a.Cout + co) * dH + oy) * dW + ox] = val;
-          } else {
-            const size_t e = (((size_t)n * dH + oy) * dW + ox) * dC + (co - dc0);
-            if (a.out_mode == OUT_ACCUM) Tr<T>::store(dptr, e, Tr<T>::load(dptr, e) + val);
-            else Tr<T>::store(dptr, e, val);
+          if (head) {
+            const DstDesc& d = a.dst[0];
+            const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
+            ((float*)d.ptr)[(((size_t)n * a.Cout + co) * d.H + oy) * d.W + ox] = val;
           }
+        }
+        if (!head) {
+          if (sizeof(T) == 4) *(float*)(otile + (ty * TW + tx) * OPITCH + cl * 4) = val;
+          else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = __builtin_bit_cast(unsigned short, b); }
         }
       }
     }
   }
   if (a.stat_slab != nullptr) {
-    __syncthreads();  // LDS is free again
-    float* red = (float*)smem;  // [wm][BN][2]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       s1[nt] += __shfl_xor(s1[nt], 32);
       s2[nt] += __shfl_xor(s2[nt], 32);
       if (h == 0) {
-        const int cl = wn * (BN / 2) + nt * 32 + r;
+        const int cl = wn * NT * 32 + nt * 32 + r;
         red[(wm * BN + cl) * 2 + 0] = s1[nt];
         red[(wm * BN + cl) * 2 + 1] = s2[nt];
       }
     }
-    __syncthreads();
-    if (tid < BN) {
-      const int co = co0 + tid;
-      if (co < a.Cout) {
-        float* slab = a.stat_slab + ((size_t)(a.slab_row0 + blockIdx.x) * a.Cout + co) * 2;
-        slab[0] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
-        slab[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+  }
+  __syncthreads();
+  if (a.stat_slab != nullptr && tid < BN) {
+    const int co = co0 + tid;
+    if (co < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      float* slab = a.stat_slab + ((size_t)(a.slab_row0 + blockIdx.x) * a.Cout + co) * 2;
+      slab[0] = t1; slab[1] = t2;
+    }
+  }
+  if (!head) {
+    // cooperative store: every thread moves whole 16-byte channel vectors of one pixel
+    for (int v = tid; v < BM * OVPR; v += NTHREADS) {
+      const int p = v / OVPR, cvv = v % OVPR;
+      const int ty = p >> 4, tx = p & 15;
+      const int gy = y0 + ty, gx = x0 + tx;
+      const int co = co0 + cvv * VEC;
+      if (gy >= a.OH || gx >= a.OW || co >= a.Cout) continue;
+      char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W;
+#pragma unroll
+      for (int i = 1; i < MAX_SRC; ++i)
+        if (i < a.ndst && co >= a.dst[i].c0) {
+          dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W;
+        }
+      const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
+      uint4* gp = (uint4*)(dptr + ((((size_t)n * dH + oy) * dW + ox) * dC + (co - dc0)) * sizeof(T));
+      uint4 val = *(const uint4*)(otile + p * OPITCH + cvv * 16);
+      if (a.out_mode == OUT_ACCUM) {
+        const uint4 old = *gp;
+        if (sizeof(T) == 4) {
+          val.x = __float_as_uint(__uint_as_float(val.x) + __uint_as_float(old.x));
+          val.y = __float_as_uint(__uint_as_float(val.y) + __uint_as_float(old.y));
+          val.z = __float_as_uint(__uint_as_float(val.z) + __uint_as_float(old.z));
+          val.w = __float_as_uint(__uint_as_float(val.w) + __uint_as_float(old.w));
+        } else {
+          unsigned nv[4] = {val.x, val.y, val.z, val.w};
+          const unsigned ov[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = __uint_as_float(nv[i] << 16) + __uint_as_float(ov[i] << 16);
+            const float hi = __uint_as_float(nv[i] & 0xffff0000u) + __uint_as_float(ov[i] & 0xffff0000u);
+            nv[i] = pack_bf16(lo, hi);
+          }
+          val = make_uint4(nv[0], nv[1], nv[2], nv[3]);
+        }
       }
+      *gp = val;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t conv_lds_bytes(const ConvArgs& a, int BN) {
+namespace {
+
+struct Variant { int NT, WN, WM, RB; };
+
+size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* npass_out) {
+  const int TH = 4 * v.WM, BN = v.NT * 32 * v.WN, BM = TH * TW, PITCH = v.RB + 16;
   const bool single = a.ntaps == 1;
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
-  size_t abytes = ((size_t)RH * RW * PITCH + 15) & ~(size_t)15;
-  size_t total = abytes + 2 * (size_t)BN * PITCH;
-  size_t red = (size_t)2 * BN * 2 * sizeof(float);
-  return total > red ? total : red;
+  const int npix = RH * RW;
+  const int nthreads = 64 * v.WM * v.WN;
+  const int pstep = nthreads / (v.RB / 16);
+  if (npass_out) *npass_out = (npix + pstep - 1) / pstep;
+  const size_t abytes = ((size_t)npix * PITCH + 15) & ~(size_t)15;
+  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * (size_t)BN * PITCH;
+  const size_t epi = (size_t)BM * (BN * esz + 16) + (size_t)v.WM * BN * 2 * sizeof(float);
+  return main_loop > epi ? main_loop : epi;
 }
 
-int conv_num_mtiles(const ConvArgs& a) {
-  return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
-}
-
-template <typename T, int BN>
-static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t st) {
-  dim3 grid(conv_num_mtiles(a), (a.Cout + BN - 1) / BN);
-  size_t lds = conv_lds_bytes(a, BN);
+template <typename T, int NT, int WN, int WM, int RB>
+hipError_t launch_variant(const ConvArgs& a, int dbuf, size_t lds, hipStream_t st) {
+  constexpr int BN = NT * 32 * WN, TH = 4 * WM;
+  const int mtiles = a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
+  dim3 grid(mtiles, (a.Cout + BN - 1) / BN);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<T, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<T, NT, WN, WM, RB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<T, BN>), grid, dim3(NTHR), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, NT, WN, WM, RB>), grid, dim3(64 * WM * WN), lds, st, a, dbuf);
   return hipGetLastError();
+}
+
+// Tile choice: N tile from Cout, K chunk from Cin, M tile (16x16 or 8x16 pixels) from tile utilisation
+// and LDS fit (double-buffered window preferred).
+struct Choice { Variant v; int dbuf; size_t lds; };
+
+Choice choose(const ConvArgs& a, int esz) {
+  Choice c;
+  int NT, WN;
+  if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
+  const int kc128 = 128 / esz;
+  const int RB = a.Cin <= kc128 / 2 ? 64 : 128;
+  auto util = [&](int TH) {
+    const double ty = (a.OH + TH - 1) / TH, tx = (a.OW + TW - 1) / TW;
+    return (double)a.OH * a.OW / (ty * TH * tx * TW);
+  };
+  const size_t cap = 160 * 1024;
+  const int wm_first = util(8) > 1.15 * util(16) ? 2 : 4;
+  const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};
+  for (int pref_dbuf = 1; pref_dbuf >= 0; --pref_dbuf)
+    for (int k = 0; k < 2; ++k) {
+      Variant v{NT, WN, order[k], RB};
+      int npass = 0;
+      const size_t lds = variant_lds(a, v, esz, pref_dbuf, &npass);
+      const int ppt = (npass + a.ntaps - 1) / a.ntaps;
+      if (lds <= cap && (!pref_dbuf || ppt <= 4)) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
+    }
+  c.v = Variant{NT, WN, 2, RB}; c.dbuf = 0; c.lds = variant_lds(a, c.v, esz, 0, nullptr);
+  return c;
+}
+
+template <typename T>
+hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
+  const Choice c = choose(a, (int)sizeof(T));
+  if (c.lds > 160 * 1024) return hipErrorInvalidValue;
+  const Variant& v = c.v;
+#define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
+  if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, c.lds, st);
+  OCTSEG_CASE(2, 2, 4, 128)
+  OCTSEG_CASE(2, 2, 2, 128)
+  OCTSEG_CASE(1, 2, 4, 128)
+  OCTSEG_CASE(1, 2, 2, 128)
+  OCTSEG_CASE(1, 1, 4, 128)
+  OCTSEG_CASE(1, 1, 2, 128)
+  OCTSEG_CASE(2, 2, 4, 64)
+  OCTSEG_CASE(2, 2, 2, 64)
+  OCTSEG_CASE(1, 2, 4, 64)
+  OCTSEG_CASE(1, 2, 2, 64)
+  OCTSEG_CASE(1, 1, 4, 64)
+  OCTSEG_CASE(1, 1, 2, 64)
+#undef OCTSEG_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+int conv_num_mtiles(const ConvArgs& a, int dtype) {
+  const Choice c = choose(a, (int)dtype_size(dtype));
+  const int TH = 4 * c.v.WM;
+  return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
 }
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   if (a.ntaps <= 0) return hipSuccess;
-  const bool wide = a.Cout > 64;
-  if (dtype == DT_F32) return wide ? launch_conv_t<float, 128>(a, st) : launch_conv_t<float, 64>(a, st);
-  return wide ? launch_conv_t<bf16_t, 128>(a, st) : launch_conv_t<bf16_t, 64>(a, st);
+  if (dtype == DT_F32) return dispatch<float>(a, st);
+  return dispatch<bf16_t>(a, st);
 }
 
 }  // namespace octseg

@@ -5,8 +5,7 @@
 namespace octseg {
 
 // conv_mfma.hip
-size_t conv_lds_bytes(const ConvArgs& a, int BN);
-int conv_num_mtiles(const ConvArgs& a);
+int conv_num_mtiles(const ConvArgs& a, int dtype);  // M tiles (= BN-stat slab rows) of a launch
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
 
 // wgrad_mfma.hip

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -33,7 +34,7 @@ static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // bench.py brackets every MFMA launch with HIP events on the launch stream (octseg_profile_start /
 // _stop); classes: 0 conv forward, 1 conv data-gradient, 2 weight gradient.
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; std::string name; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
@@ -45,9 +46,9 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
   hipStream_t st; ProfRec r; bool on;
-  ProfScope(int kind, double flops, hipStream_t s) : st(s), on(g_prof_on) {
+  ProfScope(int kind, double flops, hipStream_t s, const std::string& name = std::string()) : st(s), on(g_prof_on) {
     if (!on) return;
-    r.kind = kind; r.flops = flops; r.a = prof_event(); r.b = prof_event();
+    r.kind = kind; r.flops = flops; r.name = name; r.a = prof_event(); r.b = prof_event();
     if (!r.a || !r.b) { on = false; return; }
     (void)hipEventRecord(r.a, st);
   }
@@ -421,7 +422,7 @@ static int build_plan(octseg_plan* P) {
       std::vector<ConvArgs> la;
       fwd_launches(g, la);
       int rows = 0;
-      for (auto& a : la) rows += conv_num_mtiles(a);
+      for (auto& a : la) rows += conv_num_mtiles(a, P->dtype);
       P->bns[L.bn].rows = rows;
       slab = std::max(slab, (size_t)rows * L.Cout * 2 * sizeof(float));
     }
@@ -534,8 +535,8 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.dst[0] = d;
           a.stat_slab = (L.bn >= 0 && E.train) ? (float*)(E.ws + P->slab_off) : nullptr;
           a.slab_row0 = row0;
-          row0 += conv_num_mtiles(a);
-          ProfScope ps(0, 2.0 * layer_macs(L) / (double)la.size(), E.st);
+          row0 += conv_num_mtiles(a, P->dtype);
+          ProfScope ps(0, 2.0 * layer_macs(L) / (double)la.size(), E.st, L.name);
           HIPCHK(launch_conv(P->dtype, a, E.st));
         }
         break;
@@ -620,7 +621,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.nsrc = E.fill_srcs(L, a.src);
       a.dy = dy; a.dyC = dyC;
       a.dW = E.grads + P->params[L.w].off;
-      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), E.st);
+      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), E.st, L.name);
       HIPCHK(launch_wgrad(P->dtype, a, E.st));
     }
   }
@@ -658,7 +659,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     a.ndst = nd;
     a.out_mode = OUT_ACCUM;
     a.bias = nullptr; a.stat_slab = nullptr;
-    ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st);
+    ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st, L.name);
     HIPCHK(launch_conv(P->dtype, a, E.st));
   }
   if (up_src >= 0) {
@@ -794,11 +795,17 @@ int octseg_profile_stop(double* out) {
   if (!out) return fail(OCTSEG_BAD_ARG, "null argument");
   HIPCHK(hipDeviceSynchronize());
   for (int i = 0; i < 9; ++i) out[i] = 0.0;
+  FILE* dump = nullptr;
+  if (const char* path = getenv("OCTSEG_PROFILE_DUMP")) dump = fopen(path, "w");
+  if (dump) fprintf(dump, "layer,class,ms,gflop,tflops\n");
   for (auto& r : g_prof) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
     out[3 * r.kind] += ms; out[3 * r.kind + 1] += r.flops; out[3 * r.kind + 2] += 1.0;
+    if (dump) fprintf(dump, "%s,%s,%.4f,%.3f,%.1f\n", r.name.c_str(), r.kind == 0 ? "fwd" : r.kind == 1 ? "dgrad" : "wgrad", ms,
+                      r.flops / 1e9, ms > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
   }
+  if (dump) fclose(dump);
   for (auto& r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
   g_prof.clear();
   return OCTSEG_OK;

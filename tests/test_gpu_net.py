@@ -27,12 +27,22 @@ NETS = [
 DEEP = ('resnet50', 'resnet101')
 
 
-def _oracle(arch, enc, classes, seed=7):
+def _oracle(arch, enc, classes, seed=7, kinkfree=False):
+    """Seeded oracle net with non-trivial BN parameters.  kinkfree=True pushes every BN bias to +-8
+    (per channel): each pre-activation is then >= ~4 sigma away from the ReLU kink, so channels are
+    either always on or always off and the gradient is a smooth function of the fp32 rounding."""
     from oracle import create_model
     from oracle.nets import randomize_bn
     torch.manual_seed(seed)
     m = create_model(arch, enc, classes=classes)
     randomize_bn(m, seed)
+    if kinkfree:
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    sign = (torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1
+                    mod.bias.copy_(8.0 * sign)
     with torch.no_grad():  # non-zero biases so the bias paths are exercised
         for n, p in m.named_parameters():
             if n.endswith('.bias') and p.dim() == 1 and 'segmentation_head' in n:
@@ -58,46 +68,50 @@ def _grad_report(grads, ref):
     return num / (da ** 0.5 * db ** 0.5 + 1e-30), worst, worst_name
 
 
-@pytest.mark.parametrize('cfg', NETS, ids=['-'.join(map(str, c)) for c in NETS])
-def test_train_step_parity_fp32(cuda, cfg):
-    """Forward quantities must match on every seed.  Gradients of a ReLU net are only comparable away
-    from kinks: one pre-activation within fp32 rounding of 0 flips its mask on one side and BN backward
-    spreads that over the layer, so every seed must reach cosine >= 0.999 and at least one of the
-    seeds (a kink-free one) must match parameter by parameter at 2e-3."""
+def _run_pair(cuda, cfg, seed, kinkfree):
     from oct_segmentation_amd.engine import SegNet
-    from oracle import DiceLoss, get_stats
+    from oracle import DiceLoss
     arch, enc, classes, B, S = cfg
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    strict_ok = False
-    for seed in range(11, 23):
-        ref = _oracle(arch, enc, classes)
-        net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32)
-        net.load_state_dict(ref.state_dict())
-        img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
-        ref.train()
-        logits_ref = ref((img - mean) / std)
-        loss_ref = DiceLoss()(logits_ref, mask)
-        loss_ref.backward()
+    ref = _oracle(arch, enc, classes, kinkfree=kinkfree)
+    net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32)
+    net.load_state_dict(ref.state_dict())
+    img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+    ref.train()
+    logits_ref = ref((img - mean) / std)
+    loss_ref = DiceLoss()(logits_ref, mask)
+    loss_ref.backward()
+    net.train()
+    loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True,
+                                             mean=mean.flatten().tolist(), std=std.flatten().tolist())
+    torch.cuda.synchronize()
+    return ref, net, mask, logits_ref.detach(), loss_ref, logits.cpu(), loss, stats
 
-        net.train()
-        loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True,
-                                                 mean=mean.flatten().tolist(), std=std.flatten().tolist())
-        torch.cuda.synchronize()
-        lg = logits.cpu()
-        scale = logits_ref.detach().abs().max().item()
-        err = (lg - logits_ref.detach()).abs().max().item()
+
+@pytest.mark.parametrize('cfg', NETS, ids=['-'.join(map(str, c)) for c in NETS])
+def test_train_step_parity_fp32(cuda, cfg):
+    """Random BN parameters (ReLU kinks present): logits 1e-4, loss 1e-5, masks / confusion counts exact,
+    running statistics 1e-4.  Gradients of a ReLU net are only comparable away from kinks (one
+    pre-activation within fp32 rounding of 0 flips its mask on one side and BN backward spreads that
+    over the layer), so here they are held to the global cosine; the strict parameter-by-parameter
+    check lives in test_gradients_kinkfree_fp32."""
+    from oracle import get_stats
+    arch, enc, classes, B, S = cfg
+    for seed in (11, 12):
+        ref, net, mask, logits_ref, loss_ref, lg, loss, stats = _run_pair(cuda, cfg, seed, kinkfree=False)
+        scale = logits_ref.abs().max().item()
+        err = (lg - logits_ref).abs().max().item()
         print(f'{cfg} seed {seed}: logits max|d|={err:.3e} (scale {scale:.3e}) loss {loss.item():.7f} vs {loss_ref.item():.7f}')
         tol = (2e-4 if enc in DEEP else 1e-4) * max(1.0, scale)
         assert err <= tol
         assert abs(loss.item() - loss_ref.item()) <= 1e-5
         # thresholded masks: bit-exact except where the oracle's logit is within the fp32 parity band of 0
-        pm, pr = lg > 0, logits_ref.detach() > 0
-        near = logits_ref.detach().abs() < tol
+        pm, pr = lg > 0, logits_ref > 0
+        near = logits_ref.abs() < tol
         assert bool(((pm == pr) | near).all())
         tp, fp, fn, tn = get_stats((lg.sigmoid() > 0.5).long(), mask.long())
         assert torch.equal(stats.cpu(), torch.stack([tp, fp, fn, tn], dim=-1))
-        # BN running statistics
         sd, sd_ref = net.state_dict(), ref.state_dict()
         worst = 0.0
         for k, v in sd_ref.items():
@@ -107,10 +121,22 @@ def test_train_step_parity_fp32(cuda, cfg):
         cos, worst_g, name = _grad_report(net.named_grads(), ref)
         print(f'{cfg} seed {seed}: grad cosine {cos:.7f} worst per-param err {worst_g:.3e} ({name})')
         assert cos >= 0.999
-        if worst_g < 2e-3 or enc in DEEP:
-            strict_ok = True
-            break
-    assert strict_ok, 'no seed reached parameter-wise gradient parity'
+
+
+@pytest.mark.parametrize('cfg', NETS, ids=['-'.join(map(str, c)) for c in NETS])
+def test_gradients_kinkfree_fp32(cuda, cfg):
+    """Same nets with every BN bias at +-8: no pre-activation sits near a ReLU kink, so every
+    parameter gradient must match the oracle (error <= 2e-3 of that parameter's largest gradient)."""
+    arch, enc, classes, B, S = cfg
+    ref, net, mask, logits_ref, loss_ref, lg, loss, stats = _run_pair(cuda, cfg, 11, kinkfree=True)
+    scale = logits_ref.abs().max().item()
+    err = (lg - logits_ref).abs().max().item()
+    cos, worst_g, name = _grad_report(net.named_grads(), ref)
+    print(f'{cfg} kink-free: logits max|d|={err:.3e} (scale {scale:.3e}); grad cosine {cos:.8f} worst per-param err {worst_g:.3e} ({name})')
+    assert err <= 2e-4 * max(1.0, scale)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert cos >= 0.999999
+    assert worst_g < 2e-3
 
 
 @pytest.mark.parametrize('cfg', NETS[:3], ids=['-'.join(map(str, c)) for c in NETS[:3]])
