@@ -44,8 +44,10 @@ struct ConvArgs {
   int N, IH, IW;   // virtual input extent (after up)
   int OH, OW;      // output grid extent (tile iteration space)
   int ntaps;
-  signed char tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];  // input offset of each tap (pad folded in)
-  unsigned char tap_w[MAX_TAPS];                   // weight slab index of each tap
+  // int (not char) on purpose: a runtime-indexed char in the kernarg segment is fetched with a VMEM byte
+  // load whose s_waitcnt vmcnt(0) drains the whole software pipeline; dwords go through the scalar cache.
+  int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];  // input offset of each tap (pad folded in)
+  int tap_w[MAX_TAPS];                     // weight slab index of each tap
   int min_dy, min_dx, span_y, span_x;              // bounding box of the tap offsets
   int istride;     // input coord = grid * istride + tap offset
   const void* W;   // [wtaps][Cout][Cin] T  (Cin contiguous)
@@ -66,8 +68,8 @@ struct WgradArgs {
   int N, IH, IW;
   int OH, OW;       // grid extent of dy that is iterated
   int ntaps;
-  signed char tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
-  unsigned char tap_w[MAX_TAPS];
+  int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
+  int tap_w[MAX_TAPS];
   int min_dy, min_dx, span_y, span_x;
   int istride;
   const void* dy;   // NHWC T, [N][DH][DW][dyC]

@@ -164,6 +164,8 @@ struct WindowStager {
       for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
     }
   }
+  // Branch-free: the address is clamped into the tensor so the load is unconditional (the compiler can
+  // then keep it in flight across the MFMA block); out-of-range elements are zeroed in write().
   __device__ __forceinline__ uint4 load(int pass, int n, int gy0, int gx0, int smul, int RW, int npix, float inv_rw,
                                         int IH, int IW, bool& ok) const {
     const int hp = pass * PSTEP + p0;
@@ -171,19 +173,16 @@ struct WindowStager {
     const int hx = hp - hy * RW;
     const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
     ok = cvalid && hp < npix && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ok) {
-      const size_t e = (((size_t)n * s.H + (iy >> s.up)) * s.W + (ix >> s.up)) * s.C + s.cl;
-      v = *(const uint4*)(s.ptr + e * sizeof(T));
-    }
-    return v;
+    const int iyc = min(max(iy, 0), IH - 1), ixc = min(max(ix, 0), IW - 1);
+    const size_t e = (((size_t)n * s.H + (iyc >> s.up)) * s.W + (ixc >> s.up)) * s.C + s.cl;
+    return *(const uint4*)(s.ptr + e * sizeof(T));
   }
-  __device__ __forceinline__ void write(char* lds, int pass, int npix, uint4 v, bool ok) const {
+  // unconditional store: the LDS window is padded to whole passes
+  __device__ __forceinline__ void write(char* lds, int pass, uint4 v, bool ok) const {
     const int hp = pass * PSTEP + p0;
-    if (hp < npix) {
-      if (ok && has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
-      *(uint4*)(lds + hp * PITCH + cv * 16) = v;
-    }
+    if (has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    *(uint4*)(lds + hp * PITCH + cv * 16) = v;
   }
 };
 

@@ -24,6 +24,8 @@
 #include "conv_common.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace octseg {
 
 template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS = RB / 32, VPR = RB / 16; };
@@ -40,7 +42,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   constexpr int PITCH = ConvCfg<RB>::PITCH, KSTEPS = ConvCfg<RB>::KSTEPS, VPR = ConvCfg<RB>::VPR;
   constexpr int BVEC = BN * VPR;                              // 16-byte vectors of one weight slab
   constexpr int BPT = (BVEC + NTHREADS - 1) / NTHREADS;       // per thread
-  constexpr int BBYTES = BN * PITCH;
+  constexpr int BROWS = BPT * NTHREADS / VPR;                 // >= BN: every thread owns a slot
+  constexpr int BBYTES = BROWS * PITCH;
   constexpr int MAXP = 4;                                     // window passes prefetched per tap
   typedef WindowStager<T, RB, NTHREADS> Stager;
 
@@ -64,11 +67,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
   const int npass = (npix + Stager::PSTEP - 1) / Stager::PSTEP;
-  const int ppt = (npass + a.ntaps - 1) / a.ntaps;            // passes prefetched per tap (<= MAXP by host check)
   const float inv_rw = 1.0f / (float)RW;
   const int gy0 = y0 * a.istride + a.min_dy, gx0 = x0 * a.istride + a.min_dx;
 
-  const int abytes = (npix * PITCH + 15) & ~15;
+  const int abytes = npass * Stager::PSTEP * PITCH;   // rows padded to whole passes (unconditional stores)
   char* ldsA = smem;                                  // [1 or 2] windows
   char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slabs
 
@@ -98,16 +100,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       const int v = tid + i * NTHREADS;
       const int row = v / VPR, cv = v % VPR;
       const int co = co0 + row, c = chunk * KC + cv * VEC;
-      regs[i] = make_uint4(0, 0, 0, 0);
-      if (v < BVEC && co < a.Cout && c < a.Cin)
-        regs[i] = *(const uint4*)(Wp + (((size_t)tapw * a.Cout + co) * a.Cin + c) * sizeof(T));
+      // unconditional load from a clamped (always valid) address; invalid lanes are zeroed in writeB
+      const int coc = min(co, a.Cout - 1), cc = c < a.Cin ? c : 0;
+      regs[i] = *(const uint4*)(Wp + (((size_t)tapw * a.Cout + coc) * a.Cin + cc) * sizeof(T));
     }
   };
-  auto writeB = [&](char* dstb, const uint4* regs) {
+  // unconditional stores (the slab has BROWS >= BN rows so that every thread owns a slot): a store
+  // under a lane condition would hide its s_waitcnt from the loop back-edge and the compiler would
+  // then drain vmcnt(0) ahead of the next iteration's MFMAs.
+  auto writeB = [&](char* dstb, int chunk, const uint4* regs) {
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int v = tid + i * NTHREADS;
-      if (v < BVEC) *(uint4*)(dstb + (v / VPR) * PITCH + (v % VPR) * 16) = regs[i];
+      const bool okb = (co0 + v / VPR) < a.Cout && (chunk * KC + (v % VPR) * VEC) < a.Cin;
+      *(uint4*)(dstb + (v / VPR) * PITCH + (v % VPR) * 16) = okb ? regs[i] : make_uint4(0, 0, 0, 0);
     }
   };
   auto stage_full = [&](const Stager& sg, char* dst) {
@@ -115,77 +121,90 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       uint4 v[MAXP];
       bool ok[MAXP];
 #pragma unroll
-      for (int u = 0; u < MAXP; ++u) v[u] = sg.load(p + u, n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, ok[u]);
+      for (int u = 0; u < MAXP; ++u) v[u] = sg.load(min(p + u, npass - 1), n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, ok[u]);
 #pragma unroll
-      for (int u = 0; u < MAXP; ++u) sg.write(dst, p + u, npix, v[u], ok[u]);
+      for (int u = 0; u < MAXP; ++u) sg.write(dst, min(p + u, npass - 1), v[u], ok[u]);
+    }
+  };
+  auto mma_tap = [&](const char* awin, const char* bsl, int toff) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      uint4 af[2], bf[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const uint4*)(bsl + bbase[nt] + ks * 32);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[mt], bf[nt], acc[mt][nt]);
     }
   };
 
   // ---------------- prologue: window of chunk 0 + first weight slab ----------------
-  Stager cur;
-  cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
-  stage_full(cur, ldsA);
   {
+    Stager cur;
+    cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
+    stage_full(cur, ldsA);
     uint4 regs[BPT];
     loadB(a.tap_w[0], 0, regs);
-    writeB(ldsB, regs);
+    writeB(ldsB, 0, regs);
   }
   __syncthreads();
 
-  int it = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const bool has_next = chunk + 1 < nchunks;
-    Stager nxt;
-    if (has_next) nxt.setup(a.src, a.nsrc, a.Cin, chunk + 1, tid);
-    const char* awin = ldsA + ((dbuf && (chunk & 1)) ? abytes : 0);
-    char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
-    for (int t = 0; t < a.ntaps; ++t, ++it) {
-      // ---- issue the global loads that will be consumed one iteration / one chunk later ----
-      uint4 nregs[BPT];
-      const bool more_b = (t + 1 < a.ntaps) || has_next;
-      if (more_b) {
-        if (t + 1 < a.ntaps) loadB(a.tap_w[t + 1], chunk, nregs);
-        else loadB(a.tap_w[0], chunk + 1, nregs);
-      }
-      uint4 av[MAXP];
-      bool aok[MAXP];
-      const bool pre_a = dbuf && has_next;
-      if (pre_a) {
+  // ---------------- main loop ----------------
+  // PPT = window passes of the NEXT chunk prefetched per tap (1 for multi-tap convs, 4 for 1x1);
+  // every load and every LDS store of the pipeline is unconditional: indices are clamped instead
+  // (re-staging the last pass / the last chunk again is harmless).
+  auto run = [&](auto ppt_c, auto dbuf_c) {
+    constexpr int PPT = decltype(ppt_c)::value;
+    constexpr bool DBUF = decltype(dbuf_c)::value;
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool has_next = chunk + 1 < nchunks;
+      Stager nxt;
+      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid);
+      const char* awin = ldsA + ((DBUF && (chunk & 1)) ? abytes : 0);
+      char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
+      for (int t = 0; t < a.ntaps; ++t, ++it) {
+        // next iteration's weight slab (clamped on the very last iteration)
+        const bool wrap = t + 1 == a.ntaps;
+        const int ntap = wrap ? 0 : t + 1;
+        const int nchk = wrap ? min(chunk + 1, nchunks - 1) : chunk;
+        uint4 nregs[BPT];
+        loadB(a.tap_w[ntap], nchk, nregs);
+        uint4 av[PPT];
+        bool aok[PPT];
+        if constexpr (DBUF) {
 #pragma unroll
-        for (int u = 0; u < MAXP; ++u) {
-          aok[u] = false;
-          av[u] = make_uint4(0, 0, 0, 0);
-          if (u < ppt) av[u] = nxt.load(t * ppt + u, n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, aok[u]);
+          for (int u = 0; u < PPT; ++u)
+            av[u] = nxt.load(min(t * PPT + u, npass - 1), n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, aok[u]);
+        }
+        const int toff = single ? 0 : ((a.tap_dy[t] - a.min_dy) * RW + (a.tap_dx[t] - a.min_dx)) * PITCH;
+        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
+        // keep the consumers of the prefetched registers (BN affine, LDS stores) behind the MFMA block:
+        // hoisted in between the MFMAs they would stall the issue on loads that were only just sent
+        __builtin_amdgcn_sched_barrier(0);
+        writeB(ldsB + ((it + 1) & 1) * BBYTES, nchk, nregs);
+        if constexpr (DBUF) {
+#pragma unroll
+          for (int u = 0; u < PPT; ++u) nxt.write(anext, min(t * PPT + u, npass - 1), av[u], aok[u]);
+        }
+        __syncthreads();
+      }
+      if constexpr (!DBUF) {
+        if (has_next) {  // window does not fit twice: restage in place (all waves passed the barrier)
+          stage_full(nxt, ldsA);
+          __syncthreads();
         }
       }
-      // ---- MFMAs of (chunk, tap t) ----
-      const int toff = single ? 0 : ((a.tap_dy[t] - a.min_dy) * RW + (a.tap_dx[t] - a.min_dx)) * PITCH;
-      const char* bsl = ldsB + (it & 1) * BBYTES;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        uint4 af[2], bf[NT];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const uint4*)(bsl + bbase[nt] + ks * 32);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[mt], bf[nt], acc[mt][nt]);
-      }
-      // ---- land the prefetched data in the other LDS buffers ----
-      if (more_b) writeB(ldsB + ((it + 1) & 1) * BBYTES, nregs);
-      if (pre_a) {
-#pragma unroll
-        for (int u = 0; u < MAXP; ++u)
-          if (u < ppt) nxt.write(anext, t * ppt + u, npix, av[u], aok[u]);
-      }
-      __syncthreads();
     }
-    if (!dbuf && has_next) {  // window does not fit twice: restage in place (all waves passed the barrier)
-      stage_full(nxt, ldsA);
-      __syncthreads();
-    }
+  };
+  if (dbuf) {
+    if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
+    else run(std::integral_constant<int, 1>{}, std::true_type{});
+  } else {
+    run(std::integral_constant<int, 1>{}, std::false_type{});
   }
 
   // ---------------- epilogue ----------------
@@ -305,8 +324,12 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
   const int nthreads = 64 * v.WM * v.WN;
   const int pstep = nthreads / (v.RB / 16);
   if (npass_out) *npass_out = (npix + pstep - 1) / pstep;
-  const size_t abytes = ((size_t)npix * PITCH + 15) & ~(size_t)15;
-  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * (size_t)BN * PITCH;
+  const int npass = (npix + pstep - 1) / pstep;
+  const size_t abytes = (size_t)npass * pstep * PITCH;
+  const int vpr = v.RB / 16;
+  const int bpt = (BN * vpr + nthreads - 1) / nthreads;
+  const size_t brows = (size_t)bpt * nthreads / vpr;
+  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * brows * PITCH;
   const size_t epi = (size_t)BM * (BN * esz + 16) + (size_t)v.WM * BN * 2 * sizeof(float);
   return main_loop > epi ? main_loop : epi;
 }
@@ -349,8 +372,9 @@ Choice choose(const ConvArgs& a, int esz) {
       Variant v{NT, WN, order[k], RB};
       int npass = 0;
       const size_t lds = variant_lds(a, v, esz, pref_dbuf, &npass);
-      const int ppt = (npass + a.ntaps - 1) / a.ntaps;
-      if (lds <= cap && (!pref_dbuf || ppt <= 4)) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
+      // the pipeline prefetches 1 pass per tap (4 for 1x1): the next window must fit that budget
+      const bool fits_pipe = a.ntaps == 1 ? npass <= 4 : npass <= a.ntaps;
+      if (lds <= cap && (!pref_dbuf || fits_pipe)) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
     }
   c.v = Variant{NT, WN, 2, RB}; c.dbuf = 0; c.lds = variant_lds(a, c.v, esz, 0, nullptr);
   return c;

@@ -61,7 +61,7 @@ struct ProfScope {
 }  // namespace
 
 // ================================================================ tap tables / launch geometry
-static void set_taps(signed char* tdy, signed char* tdx, unsigned char* tw, int n, int& ntaps, int& min_dy,
+static void set_taps(int* tdy, int* tdx, int* tw, int n, int& ntaps, int& min_dy,
                      int& min_dx, int& span_y, int& span_x) {
   ntaps = n;
   if (n == 0) { min_dy = min_dx = 0; span_y = span_x = 1; return; }
