@@ -21,14 +21,19 @@ namespace octseg {
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+// MAXW = window passes held in registers by the prefetch pipeline (per tap count)
+template <int NTAPS> struct WgradCfg { static constexpr int MAXW = NTAPS == 1 ? 4 : (NTAPS == 4 ? 6 : 7); };
+
 template <typename T, int NTAPS>
-__global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, const int th) {
+__global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, const int th, const int pipelined) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VEC = Tr<T>::VEC;
   constexpr int RB = 64 * (int)sizeof(T);  // 64 channels per LDS row
   constexpr int PITCH = RB + 16;
   constexpr int VPR = RB / 16;
   constexpr int PSTEP = NTHR / VPR;
+  constexpr int MAXY = 4, MAXW = WgradCfg<NTAPS>::MAXW;
+  typedef WindowStager<T, RB, NTHR> Stager;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq_m = wave >> 1, wq_n = wave & 1;
@@ -43,10 +48,12 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   const int RH = single ? th : (th - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
+  const int npw = (npix + PSTEP - 1) / PSTEP;      // window passes
+  const int npy = (th * TW + PSTEP - 1) / PSTEP;   // dy-tile passes
   const float inv_rw = 1.0f / (float)RW;
 
-  char* ldsY = smem;                          // [th*16][64 ch] dy tile
-  char* ldsX = smem + th * TW * PITCH;        // [RH*RW][64 ch] input window
+  char* ldsY = smem;                          // [npy*PSTEP][64 ch] dy tile (rows padded to whole passes)
+  char* ldsX = smem + npy * PSTEP * PITCH;    // [npw*PSTEP][64 ch] input window
 
   f32x16_t acc[NTAPS];
 #pragma unroll
@@ -74,54 +81,49 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
     xrow_step = 2 * lstride * PITCH;  // next MFMA: 2 pixels further
   }
 
-  for (int tile = blockIdx.z; tile < ntiles; tile += a.ksplit) {
-    int rem = tile;
-    const int n = rem / (tiles_x * tiles_y);
-    rem -= n * tiles_x * tiles_y;
-    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
-    const int y0 = tyi * th, x0 = txi * TW;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage dy tile (zero outside the grid / channel range) ----
-    {
-      const int cv = tid % VPR;
-      const int c = co0 + cv * VEC;
-      for (int p = tid / VPR; p < th * TW; p += PSTEP) {
-        const int ty = p >> 4, tx = p & 15;
-        const int gy = y0 + ty, gx = x0 + tx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy < a.OH && gx < a.OW && c < a.dyC) {
-          const size_t e = (((size_t)n * a.DH + gy * a.dstride + a.doy) * a.DW + gx * a.dstride + a.dox) * a.dyC + c;
-          v = *(const uint4*)((const char*)a.dy + e * sizeof(T));
-        }
-        *(uint4*)(ldsY + p * PITCH + cv * 16) = v;
-      }
-    }
-    // ---- stage the input window (64 channels starting at ci0) ----
-    stage_window<T, RB>(ldsX, a.src, a.nsrc, a.Cin, blockIdx.x, n, y0 * a.istride + a.min_dy,
-                        x0 * a.istride + a.min_dx, smul, RW, npix, inv_rw, a.IH, a.IW, tid);
-    __syncthreads();
-    // ---- MFMA over the pixels of the tile ----
+  Stager sg;  // window stager: the channel chunk is fixed for the whole kernel
+  sg.setup(a.src, a.nsrc, a.Cin, blockIdx.x, tid);
+  const int ycv = tid % VPR, yp0 = tid / VPR;
+  const int yc = co0 + ycv * VEC;
+  const bool ycok = yc < a.dyC;
+
+  struct TilePos { int n, y0, x0; };
+  auto tile_pos = [&](int tile) {
+    TilePos tp;
+    tp.n = tile / (tiles_x * tiles_y);
+    const int rem = tile - tp.n * tiles_x * tiles_y;
+    const int tyi = rem / tiles_x;
+    tp.y0 = tyi * th; tp.x0 = (rem - tyi * tiles_x) * TW;
+    return tp;
+  };
+  // branch-free dy load: clamped address, validity resolved when the vector is written to LDS
+  auto load_y = [&](const TilePos& tp, int pass, bool& ok) {
+    const int p = pass * PSTEP + yp0;
+    const int gy = tp.y0 + (p >> 4), gx = tp.x0 + (p & 15);
+    ok = ycok && p < th * TW && gy < a.OH && gx < a.OW;
+    const int gyc = min(gy, a.OH - 1), gxc = min(gx, a.OW - 1);
+    const size_t e = (((size_t)tp.n * a.DH + gyc * a.dstride + a.doy) * a.DW + gxc * a.dstride + a.dox) * a.dyC + (ycok ? yc : 0);
+    return *(const uint4*)((const char*)a.dy + e * sizeof(T));
+  };
+  auto write_y = [&](int pass, uint4 v, bool ok) {
+    *(uint4*)(ldsY + (pass * PSTEP + yp0) * PITCH + ycv * 16) = ok ? v : make_uint4(0, 0, 0, 0);
+  };
+  auto compute = [&]() {
     for (int kk = 0; kk < th; ++kk) {
       const char* yrow = ldsY + kk * TW * PITCH + ya0;
       const char* xrow = ldsX + (kk * lstride) * RW * PITCH + xa0;
       if constexpr (sizeof(T) == 2) {
-        s16x4_t y_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
-        s16x4_t y_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
-        uint4 af;
-        af.x = ((unsigned)(unsigned short)y_lo[0]) | ((unsigned)(unsigned short)y_lo[1] << 16);
-        af.y = ((unsigned)(unsigned short)y_lo[2]) | ((unsigned)(unsigned short)y_lo[3] << 16);
-        af.z = ((unsigned)(unsigned short)y_hi[0]) | ((unsigned)(unsigned short)y_hi[1] << 16);
-        af.w = ((unsigned)(unsigned short)y_hi[2]) | ((unsigned)(unsigned short)y_hi[3] << 16);
+        struct Pair { s16x4_t lo, hi; };  // two transposed 4-element reads = one 8-element MFMA fragment
+        Pair ya;
+        ya.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
+        ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
+        const uint4 af = __builtin_bit_cast(uint4, ya);
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
-          s16x4_t x_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
-          s16x4_t x_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
-          uint4 bf;
-          bf.x = ((unsigned)(unsigned short)x_lo[0]) | ((unsigned)(unsigned short)x_lo[1] << 16);
-          bf.y = ((unsigned)(unsigned short)x_lo[2]) | ((unsigned)(unsigned short)x_lo[3] << 16);
-          bf.z = ((unsigned)(unsigned short)x_hi[0]) | ((unsigned)(unsigned short)x_hi[1] << 16);
-          bf.w = ((unsigned)(unsigned short)x_hi[2]) | ((unsigned)(unsigned short)x_hi[3] << 16);
-          Tr<T>::mma(af, bf, acc[t]);
+          Pair xb;
+          xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
+          xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
+          Tr<T>::mma(af, __builtin_bit_cast(uint4, xb), acc[t]);
         }
       } else {
 #pragma unroll
@@ -134,6 +136,66 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           }
         }
       }
+    }
+  };
+
+  if (pipelined) {
+    // register-prefetch pipeline: the global loads of tile k+1 fly under the MFMAs of tile k; every
+    // load / LDS store is unconditional (clamped indices) so that no wait hides behind a branch.
+    uint4 yv[MAXY], xv[MAXW];
+    bool yok[MAXY], xok[MAXW];
+    auto load_tile = [&](int tile) {
+      const TilePos tp = tile_pos(tile);
+#pragma unroll
+      for (int u = 0; u < MAXY; ++u) yv[u] = load_y(tp, min(u, npy - 1), yok[u]);
+#pragma unroll
+      for (int u = 0; u < MAXW; ++u)
+        xv[u] = sg.load(min(u, npw - 1), tp.n, tp.y0 * a.istride + a.min_dy, tp.x0 * a.istride + a.min_dx, smul, RW, npix,
+                        inv_rw, a.IH, a.IW, xok[u]);
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+      for (int u = 0; u < MAXY; ++u) write_y(min(u, npy - 1), yv[u], yok[u]);
+#pragma unroll
+      for (int u = 0; u < MAXW; ++u) sg.write(ldsX, min(u, npw - 1), xv[u], xok[u]);
+    };
+    int tile = blockIdx.z;
+    if (tile < ntiles) {
+      load_tile(tile);
+      write_tile();
+      __syncthreads();
+      for (; tile < ntiles; tile += a.ksplit) {
+        const int nxt = tile + a.ksplit < ntiles ? tile + a.ksplit : tile;  // last round re-fetches (harmless)
+        load_tile(nxt);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // every wave is done reading the tile
+        write_tile();
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int tile = blockIdx.z; tile < ntiles; tile += a.ksplit) {
+      const TilePos tp = tile_pos(tile);
+      __syncthreads();  // previous tile fully consumed
+      for (int p = 0; p < npy; p += MAXY) {
+        uint4 v[MAXY]; bool ok[MAXY];
+#pragma unroll
+        for (int u = 0; u < MAXY; ++u) v[u] = load_y(tp, min(p + u, npy - 1), ok[u]);
+#pragma unroll
+        for (int u = 0; u < MAXY; ++u) write_y(min(p + u, npy - 1), v[u], ok[u]);
+      }
+      for (int p = 0; p < npw; p += 4) {
+        uint4 v[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = sg.load(min(p + u, npw - 1), tp.n, tp.y0 * a.istride + a.min_dy, tp.x0 * a.istride + a.min_dx, smul, RW,
+                         npix, inv_rw, a.IH, a.IW, ok[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sg.write(ldsX, min(p + u, npw - 1), v[u], ok[u]);
+      }
+      __syncthreads();
+      compute();
     }
   }
 
@@ -150,20 +212,33 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   }
 }
 
-static size_t wgrad_lds_bytes(const WgradArgs& a, int dtype, int th) {
-  const int RB = 64 * (int)dtype_size(dtype), PITCH = RB + 16;
+struct WgradGeom { int npy, npw; size_t lds; };
+static WgradGeom wgrad_geom(const WgradArgs& a, int dtype, int th) {
+  const int RB = 64 * (int)dtype_size(dtype), PITCH = RB + 16, PSTEP = NTHR / (RB / 16);
   const bool single = a.ntaps == 1;
   const int RH = single ? th : (th - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
-  return (size_t)(th * TW + RH * RW) * PITCH;
+  WgradGeom g;
+  g.npy = (th * TW + PSTEP - 1) / PSTEP;
+  g.npw = (RH * RW + PSTEP - 1) / PSTEP;
+  g.lds = (size_t)(g.npy + g.npw) * PSTEP * PITCH;
+  return g;
 }
 
 template <typename T, int NTAPS>
 static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st) {
   WgradArgs a = a0;
-  int th = 8;
-  while (th > 1 && wgrad_lds_bytes(a, dtype, th) > 150 * 1024) th >>= 1;
-  const size_t lds = wgrad_lds_bytes(a, dtype, th);
+  // largest pixel tile whose passes fit the register pipeline (MAXY / MAXW); else largest that fits LDS
+  int th = 0, pipelined = 0;
+  for (int cand = 8; cand >= 2; cand >>= 1) {
+    const WgradGeom g = wgrad_geom(a, dtype, cand);
+    if (g.npy <= 4 && g.npw <= WgradCfg<NTAPS>::MAXW && g.lds <= 150 * 1024) { th = cand; pipelined = 1; break; }
+  }
+  if (!th) {
+    th = 8;
+    while (th > 1 && wgrad_geom(a, dtype, th).lds > 150 * 1024) th >>= 1;
+  }
+  const size_t lds = wgrad_geom(a, dtype, th).lds;
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
   int ks = (1024 + gx * gy - 1) / (gx * gy);  // aim at ~1024 workgroups
@@ -177,7 +252,7 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_mfma_kernel<T, NTAPS>), dim3(gx, gy, ks), dim3(NTHR), lds, st, a, th);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<T, NTAPS>), dim3(gx, gy, ks), dim3(NTHR), lds, st, a, th, pipelined);
   return hipGetLastError();
 }
 
