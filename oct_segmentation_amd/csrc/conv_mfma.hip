@@ -14,10 +14,11 @@
 // (v_mfma_f32_32x32x16_bf16, or 4x v_mfma_f32_32x32x2_f32 = exact f32 fmaf chain for the parity
 // path).  Per channel chunk (RB bytes of K) the (tile + halo) input window is staged ONCE into LDS
 // and every tap reads its A fragments from it at a shifted address (no im2col buffer anywhere);
-// weights stream per tap through a double-buffered LDS slab.  Software pipeline: while the MFMAs of
-// (chunk c, tap t) run, the global loads of the next weight slab and of a slice of chunk c+1's
-// window are in flight (register staged, written to the other LDS buffers after the MFMAs), one
-// barrier per tap.  The epilogue adds bias, emits per-channel (sum, sumsq) partials for the
+// weights are pre-packed (pack_weight_image) into the exact, XOR-swizzled LDS image of every
+// (tap, chunk, N-tile) slab and stream through a 2-slab LDS ring by LDS-DMA (global_load_lds, no
+// VGPRs / ds_write / address math).  Software pipeline: while the MFMAs of (chunk c, tap t) run, the
+// DMA of the next slab and the register-staged load of a slice of chunk c+1's
+// window are in flight; one barrier per tap.  The epilogue adds bias, emits per-channel (sum, sumsq) partials for the
 // following BatchNorm (deterministic slab, reduced by bn_finalize), transposes the accumulators
 // through LDS and stores / accumulates whole 16-byte channel vectors.
 #include "common.h"
@@ -40,10 +41,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   constexpr int VEC = Tr<T>::VEC;
   constexpr int KC = RB / (int)sizeof(T);
   constexpr int PITCH = ConvCfg<RB>::PITCH, KSTEPS = ConvCfg<RB>::KSTEPS, VPR = ConvCfg<RB>::VPR;
-  constexpr int BVEC = BN * VPR;                              // 16-byte vectors of one weight slab
-  constexpr int BPT = (BVEC + NTHREADS - 1) / NTHREADS;       // per thread
-  constexpr int BROWS = BPT * NTHREADS / VPR;                 // >= BN: every thread owns a slot
-  constexpr int BBYTES = BROWS * PITCH;
+  constexpr int NWAVES = WM * WN;
+  constexpr int BBYTES = BN * RB;                             // one weight slab = its packed image
+  constexpr int NDMA = BBYTES / 1024;                         // 1 KiB LDS-DMA pieces per slab
+  constexpr int DPW = (NDMA + NWAVES - 1) / NWAVES;           // pieces issued per wave
+  constexpr int SWZ_DIV = 256 / RB;                           // rows per 256-byte LDS bank line
   constexpr int MAXP = 4;                                     // window passes prefetched per tap
   typedef WindowStager<T, RB, NTHREADS> Stager;
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 
   const int abytes = npass * Stager::PSTEP * PITCH;   // rows padded to whole passes (unconditional stores)
   char* ldsA = smem;                                  // [1 or 2] windows
-  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slabs
+  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slab ring
 
   f32x16_t acc[2][NT];
 #pragma unroll
@@ -88,32 +90,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     const int ty = wm * 4 + mt * 2 + (r >> 4), tx = r & 15;
     abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
   }
+  int bswz[NT];  // XOR swizzle of the 16-byte chunk index inside a slab row (matches pack_weight_image)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * NT * 32 + nt * 32 + r) * PITCH + h * 16;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wn * NT * 32 + nt * 32 + r;
+    bbase[nt] = row * RB;
+    bswz[nt] = (row / SWZ_DIV) & (VPR - 1);
+  }
 
   const int nchunks = (a.Cin + KC - 1) / KC;
   const char* Wp = (const char*)a.W;
 
-  auto loadB = [&](int tapw, int chunk, uint4* regs) {
+  const int ntiles_n = gridDim.y;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ldsB_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsB;  // LDS byte address
+  // LDS-DMA of the packed slab (tapw, chunk) of this N tile into ring slot `slot`.  Issued through
+  // inline asm: hipcc cannot prove that a builtin LDS-DMA write does not alias the ds_reads that follow
+  // (runtime ring offsets) and would drain vmcnt(0) right behind it; the asm form is invisible to its
+  // waitcnt pass and is retired by the explicit s_waitcnt in front of the barrier instead.
+  auto dmaB = [&](int tapw, int chunk, int slot) {
+    const char* slab = Wp + ((size_t)(tapw * nchunks + chunk) * ntiles_n + blockIdx.y) * BBYTES;
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int v = tid + i * NTHREADS;
-      const int row = v / VPR, cv = v % VPR;
-      const int co = co0 + row, c = chunk * KC + cv * VEC;
-      // unconditional load from a clamped (always valid) address; invalid lanes are zeroed in writeB
-      const int coc = min(co, a.Cout - 1), cc = c < a.Cin ? c : 0;
-      regs[i] = *(const uint4*)(Wp + (((size_t)tapw * a.Cout + coc) * a.Cin + cc) * sizeof(T));
-    }
-  };
-  // unconditional stores (the slab has BROWS >= BN rows so that every thread owns a slot): a store
-  // under a lane condition would hide its s_waitcnt from the loop back-edge and the compiler would
-  // then drain vmcnt(0) ahead of the next iteration's MFMAs.
-  auto writeB = [&](char* dstb, int chunk, const uint4* regs) {
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int v = tid + i * NTHREADS;
-      const bool okb = (co0 + v / VPR) < a.Cout && (chunk * KC + (v % VPR) * VEC) < a.Cin;
-      *(uint4*)(dstb + (v / VPR) * PITCH + (v % VPR) * 16) = okb ? regs[i] : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < DPW; ++j) {
+      const int idx = wave_u * DPW + j;
+      if (NDMA % NWAVES == 0 || idx < NDMA) {
+        const char* gsrc = slab + idx * 1024 + lane * 16;
+        const unsigned dst = ldsB_addr + slot * BBYTES + idx * 1024;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      }
     }
   };
   auto stage_full = [&](const Stager& sg, char* dst) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) af[mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const uint4*)(bsl + bbase[nt] + ks * 32);
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -145,11 +151,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   {
     Stager cur;
     cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
+    dmaB(a.tap_w[0], 0, 0);
     stage_full(cur, ldsA);
-    uint4 regs[BPT];
-    loadB(a.tap_w[0], 0, regs);
-    writeB(ldsB, 0, regs);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---------------- main loop ----------------
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     constexpr int PPT = decltype(ppt_c)::value;
     constexpr bool DBUF = decltype(dbuf_c)::value;
     int it = 0;
+    int tap2 = a.ntaps == 1 ? 0 : 1, chunk2 = a.ntaps == 1 ? min(1, nchunks - 1) : 0;  // slab of iteration 1
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool has_next = chunk + 1 < nchunks;
       Stager nxt;
@@ -167,12 +173,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       const char* awin = ldsA + ((DBUF && (chunk & 1)) ? abytes : 0);
       char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
       for (int t = 0; t < a.ntaps; ++t, ++it) {
-        // next iteration's weight slab (clamped on the very last iteration)
-        const bool wrap = t + 1 == a.ntaps;
-        const int ntap = wrap ? 0 : t + 1;
-        const int nchk = wrap ? min(chunk + 1, nchunks - 1) : chunk;
-        uint4 nregs[BPT];
-        loadB(a.tap_w[ntap], nchk, nregs);
+        // window slice of the next chunk (register load) and the LDS-DMA of the next iteration's slab:
+        // both fly under the MFMAs below and are retired in front of the barrier.
         uint4 av[PPT];
         bool aok[PPT];
         if constexpr (DBUF) {
@@ -180,17 +182,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
           for (int u = 0; u < PPT; ++u)
             av[u] = nxt.load(min(t * PPT + u, npass - 1), n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, aok[u]);
         }
+        dmaB(a.tap_w[tap2], chunk2, (it + 1) & 1);
         const int toff = single ? 0 : ((a.tap_dy[t] - a.min_dy) * RW + (a.tap_dx[t] - a.min_dx)) * PITCH;
         mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
-        // keep the consumers of the prefetched registers (BN affine, LDS stores) behind the MFMA block:
-        // hoisted in between the MFMAs they would stall the issue on loads that were only just sent
+        // keep the consumers of the prefetched registers (BN affine, LDS stores) behind the MFMA block
         __builtin_amdgcn_sched_barrier(0);
-        writeB(ldsB + ((it + 1) & 1) * BBYTES, nchk, nregs);
         if constexpr (DBUF) {
 #pragma unroll
           for (int u = 0; u < PPT; ++u) nxt.write(anext, min(t * PPT + u, npass - 1), av[u], aok[u]);
         }
-        __syncthreads();
+        // the slab of iteration it+1 (and this wave's LDS stores) must have landed before anyone passes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // (tap, chunk) cursor of the next iteration's slab (clamped at the very end)
+        if (++tap2 == a.ntaps) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
       }
       if constexpr (!DBUF) {
         if (has_next) {  // window does not fit twice: restage in place (all waves passed the barrier)
@@ -317,6 +324,7 @@ struct Variant { int NT, WN, WM, RB; };
 
 size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* npass_out) {
   const int TH = 4 * v.WM, BN = v.NT * 32 * v.WN, BM = TH * TW, PITCH = v.RB + 16;
+  (void)PITCH;
   const bool single = a.ntaps == 1;
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
@@ -326,10 +334,7 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
   if (npass_out) *npass_out = (npix + pstep - 1) / pstep;
   const int npass = (npix + pstep - 1) / pstep;
   const size_t abytes = (size_t)npass * pstep * PITCH;
-  const int vpr = v.RB / 16;
-  const int bpt = (BN * vpr + nthreads - 1) / nthreads;
-  const size_t brows = (size_t)bpt * nthreads / vpr;
-  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * brows * PITCH;
+  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * (size_t)BN * v.RB;
   const size_t epi = (size_t)BM * (BN * esz + 16) + (size_t)v.WM * BN * 2 * sizeof(float);
   return main_loop > epi ? main_loop : epi;
 }
@@ -405,6 +410,17 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+ConvPackInfo conv_pack_info(const ConvArgs& a, int dtype) {
+  const Choice c = choose(a, (int)dtype_size(dtype));
+  ConvPackInfo p;
+  p.BN = c.v.NT * 32 * c.v.WN;
+  p.RB = c.v.RB;
+  const int KC = p.RB / (int)dtype_size(dtype);
+  p.nchunks = (a.Cin + KC - 1) / KC;
+  p.ntiles = (a.Cout + p.BN - 1) / p.BN;
+  return p;
+}
 
 int conv_num_mtiles(const ConvArgs& a, int dtype) {
   const Choice c = choose(a, (int)dtype_size(dtype));

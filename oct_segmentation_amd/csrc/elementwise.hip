@@ -607,40 +607,44 @@ hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void*
 }
 
 // ------------------------------------------------------------------ weight packing
-// master fp32 [taps][O][I]  ->  wT [taps][O][I] (T)  and  wTt [taps][I][OP] (T, transposed, zero padded)
+// One thread per 16-byte vector of the image.  image[wtap][chunk][ntile][row][q] holds the logical
+// chunk (q ^ swz(row)) of output row ntile*BN+row, K range chunk*KC.. (see conv_mfma.hip: the same
+// XOR is applied when the MFMA B fragments are read, so the slab can be DMA-copied linearly).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, void* wT, void* wTt, int taps, int O, int I, int OP) {
-  __shared__ float tile[32][33];
-  const int tap = blockIdx.z;
-  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int k = ty; k < 32; k += 8) {
-    const int o = o0 + k, i = i0 + tx;
-    float v = 0.f;
-    if (o < O && i < I) {
-      v = w[((size_t)tap * O + o) * I + i];
-      if (wT) {
-        if (sizeof(T) == 4) ((float*)wT)[((size_t)tap * O + o) * I + i] = v;
-        else { __bf16 h = (__bf16)v; ((bf16_t*)wT)[((size_t)tap * O + o) * I + i] = __builtin_bit_cast(unsigned short, h); }
-      }
+__global__ __launch_bounds__(256) void pack_image_kernel(const float* w, void* img, int taps, int O, int I, int transpose,
+                                                         int BN, int RB, int nchunks, int ntiles) {
+  constexpr int VEC = EV<T>::VEC;
+  const int VPR = RB / 16, KC = RB / (int)sizeof(T), swz_div = 256 / RB;
+  const int rows = transpose ? I : O, K = transpose ? O : I;
+  const size_t total = (size_t)taps * nchunks * ntiles * BN * VPR;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+    size_t rem = v;
+    const int q = (int)(rem % VPR); rem /= VPR;
+    const int row = (int)(rem % BN); rem /= BN;
+    const int nt = (int)(rem % ntiles); rem /= ntiles;
+    const int chunk = (int)(rem % nchunks);
+    const int tap = (int)(rem / nchunks);
+    const int lq = q ^ ((row / swz_div) & (VPR - 1));
+    const int co = nt * BN + row, c0 = chunk * KC + lq * VEC;
+    float x[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int c = c0 + i;
+      float val = 0.f;
+      if (co < rows && c < K) val = transpose ? w[((size_t)tap * O + c) * I + co] : w[((size_t)tap * O + co) * I + c];
+      x[i] = val;
     }
-    tile[k][tx] = v;
+    stv<T>(img, v, EV<T>::pack(x));
   }
-  __syncthreads();
-  if (wTt)
-    for (int k = ty; k < 32; k += 8) {
-      const int i = i0 + k, o = o0 + tx;
-      if (i < I && o < OP) {
-        const float v = tile[tx][k];
-        if (sizeof(T) == 4) ((float*)wTt)[((size_t)tap * I + i) * OP + o] = v;
-        else { __bf16 h = (__bf16)v; ((bf16_t*)wTt)[((size_t)tap * I + i) * OP + o] = __builtin_bit_cast(unsigned short, h); }
-      }
-    }
 }
-hipError_t launch_pack_weights(int dtype, const float* w, void* wT, void* wTt, int taps, int O, int I, int OP, hipStream_t st) {
-  dim3 grid((I + 31) / 32, (OP + 31) / 32, taps);
-  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, st, w, wT, wTt, taps, O, I, OP);
-  else hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, grid, dim3(256), 0, st, w, wT, wTt, taps, O, I, OP);
+hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int taps, int O, int I, int transpose,
+                                    const ConvPackInfo& p, hipStream_t st) {
+  const size_t total = (size_t)taps * p.nchunks * p.ntiles * p.BN * (p.RB / 16);
+  const int gr = grid_for(total, 256, 4096);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(pack_image_kernel<float>, dim3(gr), dim3(256), 0, st, w, img, taps, O, I, transpose, p.BN, p.RB, p.nchunks, p.ntiles);
+  else
+    hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, w, img, taps, O, I, transpose, p.BN, p.RB, p.nchunks, p.ntiles);
   return hipGetLastError();
 }
 

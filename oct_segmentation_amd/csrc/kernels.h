@@ -6,6 +6,13 @@ namespace octseg {
 
 // conv_mfma.hip
 int conv_num_mtiles(const ConvArgs& a, int dtype);  // M tiles (= BN-stat slab rows) of a launch
+// Layout of the packed weight image a launch expects in ConvArgs::W:
+// [wtap][chunk][N tile][BN rows][RB bytes], zero padded, 16-byte chunks XOR-swizzled per row.
+struct ConvPackInfo { int BN, RB, nchunks, ntiles; };
+ConvPackInfo conv_pack_info(const ConvArgs& a, int dtype);
+static inline size_t conv_image_bytes(const ConvPackInfo& p, int wtaps) {
+  return (size_t)wtaps * p.nchunks * p.ntiles * p.BN * p.RB;
+}
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
 
 // wgrad_mfma.hip
@@ -78,9 +85,11 @@ hipError_t launch_dice_fwd(const DiceArgs& a, hipStream_t st);
 hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void* dlogits, int CP,
                            hipStream_t st);
 
-// weight packing: master fp32 [taps][O][I] -> T copy and T transposed copy [taps][I][OP] (OP >= O, zero padded)
-hipError_t launch_pack_weights(int dtype, const float* w, void* wT, void* wTt, int taps, int O, int I, int OP,
-                               hipStream_t st);
+// weight packing: master fp32 [taps][O][I] -> LDS-image slabs of a conv launch.  transpose = 0: rows are
+// O, K runs over I (forward);  transpose = 1: rows are I, K runs over O (data gradient); K is padded
+// to Kpad (>= the contraction length the launch uses).
+hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int taps, int O, int I, int transpose,
+                                    const ConvPackInfo& p, hipStream_t st);
 
 // fused optimizers over the flat fp32 arenas
 struct OptArgs {

@@ -243,7 +243,7 @@ struct Builder {
     L.b = bias ? param(name + ".bias", OCTSEG_P_VEC, 1, 1, Cout, 1, 0) : -1;
     L.OP = (Cout + 15) / 16 * 16;
     L.out = head ? -1 : tensor(L.N, L.OH, L.OW, Cout);
-    L.bn = -1; L.wT_off = L.wTt_off = 0;
+    L.bn = -1; L.wimg_fwd_off = L.wimg_dgrad_off = 0; L.has_dgrad = false;
     P->convs.push_back(L);
     const int ci = (int)P->convs.size() - 1;
     Op op; op.kind = OP_CONV; op.conv = ci;
@@ -401,6 +401,7 @@ static int build_plan(octseg_plan* P) {
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
 
   // ---------------- workspace layout ----------------
+  P->dlogits_C = 16;
   const size_t esz = dtype_size(P->dtype);
   size_t off = 0;
   P->act_begin = off;
@@ -413,14 +414,25 @@ static int build_plan(octseg_plan* P) {
   for (auto& bn : P->bns) { bn.ss_off = off; off += align_up((size_t)bn.C * 6 * sizeof(float)); }
   size_t slab = 0, tmp = 0;
   for (auto& L : P->convs) {
-    L.wT_off = off; off += align_up((size_t)L.R * L.S * L.Cout * L.Cin * esz);
-    if (L.stem) L.wT_off = L.wT_off;  // stem weight is [O][KP] = one tap, same size formula below
-    L.wTt_off = off; off += align_up((size_t)L.R * L.S * L.Cin * L.OP * esz);
+    Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
+    if (L.stem) { g.R = g.S = 1; g.pad = 0; }
+    const int wtaps = g.R * g.S;
+    std::vector<ConvArgs> la;
+    fwd_launches(g, la);
+    L.pk_fwd = conv_pack_info(la[0], P->dtype);
+    L.wimg_fwd_off = off; off += align_up(conv_image_bytes(L.pk_fwd, wtaps));
+    L.has_dgrad = false;
+    for (auto& s : L.srcs) L.has_dgrad = L.has_dgrad || P->tensors[s.v.t].need_grad;
+    if (L.has_dgrad) {
+      std::vector<ConvArgs> ld;
+      dgrad_launches(g, ld);
+      ConvArgs d0 = ld[0];
+      for (auto& d : ld) if (d.ntaps > 0) { d0 = d; break; }
+      d0.Cin = L.head ? P->dlogits_C : L.Cout;
+      L.pk_dgrad = conv_pack_info(d0, P->dtype);
+      L.wimg_dgrad_off = off; off += align_up(conv_image_bytes(L.pk_dgrad, wtaps));
+    }
     if (L.bn >= 0) {
-      Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
-      if (L.stem) { g.R = g.S = 1; g.pad = 0; }
-      std::vector<ConvArgs> la;
-      fwd_launches(g, la);
       int rows = 0;
       for (auto& a : la) rows += conv_num_mtiles(a, P->dtype);
       P->bns[L.bn].rows = rows;
@@ -433,7 +445,6 @@ static int build_plan(octseg_plan* P) {
   for (auto& bn : P->bns) slab = std::max(slab, (size_t)1024 * bn.C * 2 * sizeof(float));
   P->slab_off = off; P->slab_bytes = slab; off += align_up(slab);
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
-  P->dlogits_C = 16;
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)P->classes * 3 * sizeof(double));
   P->ws_bytes = off;
@@ -494,19 +505,14 @@ static int pack_all_weights(Exec& E) {
   for (auto& L : P->convs) {
     const ParamInfo& w = P->params[L.w];
     const int taps = L.stem ? 1 : L.R * L.S;
-    const int O = L.Cout, I = L.Cin;
-    void* wT = E.ws + L.wT_off;
-    void* wTt = (L.stem) ? nullptr : (void*)(E.ws + L.wTt_off);  // the stem has no data gradient
-    if (P->dtype == DT_F32 && wTt == nullptr) continue;           // f32 forward reads the master copy
-    HIPCHK(launch_pack_weights(P->dtype, E.params + w.off, P->dtype == DT_F32 ? nullptr : wT, wTt, taps, O, I, L.OP, E.st));
+    HIPCHK(launch_pack_weight_image(P->dtype, E.params + w.off, E.ws + L.wimg_fwd_off, taps, L.Cout, L.Cin, 0, L.pk_fwd, E.st));
+    if (L.has_dgrad)
+      HIPCHK(launch_pack_weight_image(P->dtype, E.params + w.off, E.ws + L.wimg_dgrad_off, taps, L.Cout, L.Cin, 1, L.pk_dgrad, E.st));
   }
   return OCTSEG_OK;
 }
 
-static const void* fwd_weight(const Exec& E, const ConvLayer& L) {
-  if (E.P->dtype == DT_F32) return E.params + E.P->params[L.w].off;
-  return E.ws + L.wT_off;
-}
+static const void* fwd_weight(const Exec& E, const ConvLayer& L) { return E.ws + L.wimg_fwd_off; }
 
 static int run_forward(Exec& E, const float* image, float* logits, int normalize, const float* mean, const float* stdv) {
   octseg_plan* P = E.P;
@@ -654,7 +660,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1;
     a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of wTt are zero
-    a.W = E.ws + L.wTt_off;
+    a.W = E.ws + L.wimg_dgrad_off;
     for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
     a.ndst = nd;
     a.out_mode = OUT_ACCUM;
@@ -875,32 +881,32 @@ static bool geom_ok(int dtype, int Cin, int Cout, int R, int S, int stride, int 
   if (transposed && !(R == 4 && stride == 2)) return false;
   return true;
 }
+static Geom op_geom(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int transposed) {
+  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
+  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  return g;
+}
 size_t octseg_conv2d_scratch_bytes(int dtype, int N, int H, int W, int Cin, int Cout, int R, int S) {
+  // upper bound over stride / transposed variants: both images use rows padded to <= 128 and K to <= 64 elements
   (void)N; (void)H; (void)W;
   const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
-  const int OP = (Cout + 15) / 16 * 16;
-  return align_up((size_t)R * S * Cout * Cin * esz) + align_up((size_t)R * S * Cin * OP * esz) +
-         align_up((size_t)N * H * W * 4 * OP * esz);  // + channel-padded copy of dy for the data gradient
+  const size_t rows_f = ((size_t)Cout + 127) / 128 * 128, k_f = ((size_t)Cin + 63) / 64 * 64;
+  const size_t rows_d = ((size_t)Cin + 127) / 128 * 128, k_d = ((size_t)Cout + 63) / 64 * 64;
+  return align_up((size_t)R * S * rows_f * k_f * esz) + align_up((size_t)R * S * rows_d * k_d * esz);
 }
 
 int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float* bias, void* y, int N, int H, int W,
                           int Cin, int Cout, int R, int S, int stride, int pad, int transposed, void* scratch, void* stream) {
   if (!geom_ok(dtype, Cin, Cout, R, S, stride, transposed)) return fail(OCTSEG_BAD_SHAPE, "unsupported conv geometry");
   hipStream_t st = (hipStream_t)stream;
-  const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
-  const void* wdev = w;
-  if (dtype != OCTSEG_F32) {
-    HIPCHK(launch_pack_weights(dtype, w, scratch, nullptr, R * S, Cout, Cin, Cout, st));
-    wdev = scratch;
-  }
-  (void)esz;
-  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
-  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  const Geom g = op_geom(N, H, W, Cin, Cout, R, S, stride, pad, transposed);
   std::vector<ConvArgs> la;
   fwd_launches(g, la);
+  const ConvPackInfo pk = conv_pack_info(la[0], dtype);
+  HIPCHK(launch_pack_weight_image(dtype, w, scratch, R * S, Cout, Cin, 0, pk, st));
   for (auto& a : la) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
-    a.src[0] = s; a.nsrc = 1; a.W = wdev; a.bias = bias;
+    a.src[0] = s; a.nsrc = 1; a.W = scratch; a.bias = bias;
     DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr;
     HIPCHK(launch_conv(dtype, a, st));
@@ -914,17 +920,18 @@ int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void*
   if (!geom_ok(dtype, Cin, Cout, R, S, stride, transposed) || Cout % v != 0) return fail(OCTSEG_BAD_SHAPE, "unsupported conv geometry");
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == OCTSEG_F32 ? 4 : 2;
-  const int OP = Cout;  // entry point requires Cout % vec == 0, so dy needs no channel padding
-  char* wTt = (char*)scratch + align_up((size_t)R * S * Cout * Cin * esz);
-  HIPCHK(launch_pack_weights(dtype, w, nullptr, wTt, R * S, Cout, Cin, OP, st));
-  Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
-  if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
+  const Geom g = op_geom(N, H, W, Cin, Cout, R, S, stride, pad, transposed);
   HIPCHK(hipMemsetAsync(dx, 0, (size_t)N * H * W * Cin * esz, st));
   std::vector<ConvArgs> ld;
   dgrad_launches(g, ld);
+  ConvArgs d0 = ld[0];
+  for (auto& d : ld) if (d.ntaps > 0) { d0 = d; break; }
+  d0.Cin = Cout;
+  const ConvPackInfo pk = conv_pack_info(d0, dtype);
+  HIPCHK(launch_pack_weight_image(dtype, w, scratch, R * S, Cout, Cin, 1, pk, st));
   for (auto& a : ld) {
     SrcDesc s; s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = Cout; s.c0 = 0; s.H = g.OH; s.W = g.OW; s.up = 0; s.relu = 0;
-    a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = wTt; a.bias = nullptr;
+    a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = scratch; a.bias = nullptr;
     DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_ACCUM; a.stat_slab = nullptr;
     HIPCHK(launch_conv(dtype, a, st));

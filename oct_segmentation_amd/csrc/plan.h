@@ -51,8 +51,10 @@ struct ConvLayer {
   int out;                  // tensor id of the raw output (or -1 for the head: external logits)
   int bn;                   // BN that follows (stats emitted by the epilogue), or -1
   int w, b;                 // param indices (b = -1: no bias)
-  size_t wT_off, wTt_off;   // byte offsets of the packed compute copies in the workspace
-  int OP;                   // padded K of the dgrad (Cout rounded up to 16)
+  size_t wimg_fwd_off, wimg_dgrad_off;   // byte offsets of the packed weight images in the workspace
+  ConvPackInfo pk_fwd, pk_dgrad;         // their layouts (tile variant of the forward / dgrad launches)
+  bool has_dgrad;
+  int OP;                   // channel count of dy as the dgrad sees it (Cout rounded up to 16)
 };
 
 enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL };

@@ -1,0 +1,35 @@
+"""Micro-benchmark of one conv shape through the single-op C ABI (GPU box).
+usage: bench_conv.py N H W Cin Cout R [stride] [mode=fwd|dgrad|wgrad] [iters]"""
+import sys
+sys.path.insert(0, '.')
+import torch
+from oct_segmentation_amd import ops
+
+N, H, W, Cin, Cout, R = map(int, sys.argv[1:7])
+stride = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+mode = sys.argv[8] if len(sys.argv) > 8 else 'fwd'
+iters = int(sys.argv[9]) if len(sys.argv) > 9 else 10
+pad = R // 2
+dev = 'cuda'
+x = torch.randn(N, H, W, Cin, device=dev).bfloat16()
+w = torch.randn(R, R, Cout, Cin, device=dev) * 0.05
+OH = (H + 2 * pad - R) // stride + 1
+dy = torch.randn(N, OH, OH, Cout, device=dev).bfloat16()
+def run():
+    if mode == 'fwd':
+        return ops.conv2d_forward(x, w, None, stride, pad)
+    if mode == 'dgrad':
+        return ops.conv2d_backward_data(dy, w, (H, W), stride, pad)
+    return ops.conv2d_backward_weight(x, dy, R, stride, pad)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+fl = 2.0 * N * OH * OH * Cout * Cin * R * R
+print(f'{mode} N{N} {H}x{W} {Cin}->{Cout} k{R} s{stride}: {ms:.3f} ms/iter (incl. weight pack) {fl / ms / 1e9:.1f} TF/s')
