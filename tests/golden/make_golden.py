@@ -1,0 +1,66 @@
+"""Generates the golden vectors under tests/golden from the CPU oracle (run here, in the build
+container: `python tests/golden/make_golden.py`).  The reference repository has no importable
+implementation of this path in this environment (segmentation_models_pytorch / torchvision / cv2 /
+pytorch_lightning are absent), so the vectors pin the ORACLE against silent edits; they are also what
+the GPU tests replay through the HIP engine (tests/test_gpu_golden.py).
+
+Each case: seeded weights (torch.manual_seed), seeded synthetic batch, train-mode forward + Dice +
+backward.  Stored: logits, loss, per-parameter sum |grad| (in named_parameters order), tp/fp/fn/tn.
+Weights are NOT stored (14-32 M floats): they are re-derived from the seed on both sides.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+CASES = {
+    # name: (arch, encoder, classes, batch, size, seed)
+    'unet_resnet18': ('unet', 'resnet18', 1, 2, 64, 101),
+    'unetplusplus_resnet18': ('unetplusplus', 'resnet18', 2, 2, 64, 102),
+    'linknet_resnet18': ('linknet', 'resnet18', 2, 2, 64, 103),
+    'unet_resnet50': ('unet', 'resnet50', 1, 2, 64, 108),
+}
+
+
+def build(arch, enc, classes, seed, kinkfree=True):
+    from oracle import create_model
+    from oracle.nets import randomize_bn
+    torch.manual_seed(seed)
+    m = create_model(arch, enc, classes=classes)
+    randomize_bn(m, seed)
+    if kinkfree:  # BN biases at +-8: gradients are smooth in the fp32 rounding (see tests/test_gpu_net.py)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.bias.copy_(8.0 * ((torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+    return m.train()
+
+
+def run_case(arch, enc, classes, B, S, seed):
+    from oracle import DiceLoss, get_stats
+    from synth import make_batch
+    m = build(arch, enc, classes, seed)
+    img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    logits = m((img - mean) / std)
+    loss = DiceLoss()(logits, mask)
+    loss.backward()
+    tp, fp, fn, tn = get_stats((logits.detach().sigmoid() > 0.5).long(), mask.long())
+    return {'logits': logits.detach().numpy(), 'loss': float(loss.item()),
+            'grad_abs_sums': np.array([p.grad.abs().sum().item() for _, p in m.named_parameters()], dtype=np.float64),
+            'stats': torch.stack([tp, fp, fn, tn], dim=-1).numpy()}
+
+
+if __name__ == '__main__':
+    for name, case in CASES.items():
+        out = run_case(*case)
+        np.savez_compressed(os.path.join(HERE, f'{name}.npz'), logits=out['logits'].astype(np.float32), loss=np.float64(out['loss']),
+                            grad_abs_sums=out['grad_abs_sums'], stats=out['stats'])
+        print(name, 'loss', out['loss'], 'logits', out['logits'].shape)
