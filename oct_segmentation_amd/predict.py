@@ -1,0 +1,74 @@
+"""Ensemble inference, host mirror of the reference's ``src/predict.py:23-101``.
+
+Per class the reference loads ``<models_dir>/<LM|FC_LC|VV>/{config.json,weights.ckpt}``, resizes every image
+to that model's ``input_size``, runs ``model.predict`` frame by frame (no normalisation, sigmoid > 0.5),
+nearest-resizes the mask to ``output_size`` and writes channel ``MODELS_META[class]['index']`` into
+``mask[:, :, CLASS_ID - 1]``.  Same semantics here; two deliberate host-side differences, both
+result-neutral: the FC_LC network is run once for its two classes instead of twice,
+and frames go through the engine in batches.  cv2 is absent in this image: resizing uses PIL (bilinear /
+nearest), so preprocessing agrees with the reference statistically, not bit for bit.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .model import CLASS_IDS, OCTSegmentationModel
+
+MODELS_META = {
+    'Lumen': {'model_dir': 'LM', 'index': 0},
+    'Lipid core': {'model_dir': 'FC_LC', 'index': 0},
+    'Fibrous cap': {'model_dir': 'FC_LC', 'index': 1},
+    'Vasa vasorum': {'model_dir': 'VV', 'index': 0},
+}
+
+
+def load_model(model_dir, device='cuda', compute_dtype=torch.bfloat16):
+    """predict.py:31-50."""
+    with open(os.path.join(model_dir, 'config.json')) as f:
+        cfg = json.load(f)
+    model = OCTSegmentationModel.load_from_checkpoint(
+        checkpoint_path=os.path.join(model_dir, 'weights.ckpt'), encoder_weights=None, arch=cfg['architecture'],
+        encoder_name=cfg['encoder'], model_name=cfg['model_name'], in_channels=3, classes=cfg['classes'],
+        map_location=device, compute_dtype=compute_dtype)
+    model.eval()
+    return model, cfg
+
+
+def preprocessing_img(img, input_size):
+    """data/utils.py:159-166: RGB -> BGR, resize to input_size (bilinear)."""
+    img = img.convert('RGB').resize((input_size, input_size), Image.BILINEAR)
+    return np.asarray(img)[:, :, ::-1].copy()
+
+
+def segment(images, masks, output_size, classes, models_dir, device='cuda', batch_size=8, compute_dtype=torch.bfloat16):
+    """predict.py:61-101.  images: list of PIL images; masks: list of zero arrays [H_out, W_out, 4]."""
+    cache = {}
+    for class_name in classes:
+        meta = MODELS_META[class_name]
+        model_dir = os.path.join(models_dir, meta['model_dir'])
+        if model_dir not in cache:
+            model, cfg = load_model(model_dir, device, compute_dtype)
+            batch = np.array([preprocessing_img(img, cfg['input_size']) for img in images])
+            preds = []
+            for i in range(0, len(batch), batch_size):
+                preds.append(model.predict(images=batch[i:i + batch_size], device=device))
+            cache[model_dir] = np.concatenate(preds, axis=0)
+            del model
+        preds = cache[model_dir]
+        for i, mask in enumerate(masks):
+            ch = preds[i][:, :, meta['index']] if preds[i].ndim > 2 else preds[i]
+            resized = np.asarray(Image.fromarray((ch * 255).astype(np.uint8)).resize(tuple(output_size), Image.NEAREST)) / 255.0
+            mask[:, :, CLASS_IDS[class_name] - 1] = resized
+    return masks
+
+
+def data_processing(image_paths, output_size):
+    """data/utils.py:169-192 without the directory creation."""
+    images, masks = [], []
+    for p in image_paths:
+        images.append(Image.open(p).resize(tuple(output_size)))
+        masks.append(np.zeros((output_size[0], output_size[1], 4)))
+    return images, masks

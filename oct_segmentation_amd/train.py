@@ -1,0 +1,59 @@
+"""Thin training loop standing in for ``pl.Trainer.fit`` in ``src/models/smp/train.py:25-134`` (Lightning,
+W&B and the file dataset are out of scope): builds ``OCTSegmentationModel`` from a train.yaml-style config,
+steps it on batches from any iterable of ``(img [B,3,S,S] f32 0..255 BGR, mask [B,C,S,S] f32)`` and writes the
+reference's ``config.json`` + ``weights.ckpt`` pair.  Data parallel when launched under torchrun."""
+import json
+import os
+
+import torch
+
+from .metrics import aggregate_epoch
+from .model import OCTSegmentationModel
+from . import parallel
+
+
+def write_model_config(cfg, model_dir):
+    """train.py:105-119."""
+    os.makedirs(model_dir, exist_ok=True)
+    with open(os.path.join(model_dir, 'config.json'), 'w') as f:
+        json.dump({'model_name': f"{cfg['architecture']}_{cfg['encoder']}", 'architecture': cfg['architecture'],
+                   'encoder': cfg['encoder'], 'input_size': cfg['input_size'], 'classes': list(cfg['classes']),
+                   'batch_size': cfg['batch_size'], 'optimizer': cfg['optimizer'], 'lr': cfg['lr']}, f, indent=2)
+
+
+def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dt = torch.float32 if str(cfg.get('compute_dtype', 'bf16')) in ('fp32', 'float32') else torch.bfloat16
+    model = OCTSegmentationModel(cfg['architecture'], cfg['encoder'], f"{cfg['architecture']}_{cfg['encoder']}", 3,
+                                 cfg['classes'], lr=cfg['lr'], weight_decay=cfg['weight_decay'],
+                                 optimizer_name=cfg['optimizer'], input_size=cfg['input_size'], device=device, compute_dtype=dt)
+    net = model.model
+    if world > 1:
+        parallel.broadcast_parameters(net)
+    opt = model.configure_optimizers()
+    history = []
+    for epoch in range(1, int(cfg['epochs']) + 1):
+        model.train()
+        model.training_step_outputs.clear()
+        for img, mask in train_batches:
+            if world > 1:
+                parallel.broadcast_buffers(net)
+            loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
+                                                     grad_scale=1.0 / world)
+            if world > 1:
+                parallel.allreduce_gradients(net, world, average=False)
+            opt.step()
+            from .metrics import get_metrics_from_stats
+            model.training_step_outputs.append(get_metrics_from_stats(stats, loss))
+        row = {'epoch': epoch, 'train': aggregate_epoch(model.training_step_outputs)}
+        if val_batches is not None:
+            model.eval()
+            model.validation_step_outputs.clear()
+            for batch in val_batches:
+                model.validation_step(batch)
+            row['test'] = aggregate_epoch(model.validation_step_outputs)   # the reference calls the split 'test'
+        history.append(row)
+    if model_dir is not None and int(os.environ.get('RANK', '0')) == 0:
+        write_model_config(cfg, model_dir)
+        model.save_checkpoint(os.path.join(model_dir, 'weights.ckpt'), epoch=len(history))
+    return model, history

@@ -1,0 +1,116 @@
+"""GPU tests of the host mirror of the reference API: training_step + loss.backward() through autograd,
+torch optimizer vs fused optimizer on the arena, checkpoint round trip in the reference key space, the
+un-normalised predict() path and the segment() ensemble (channel mapping, FC_LC shared checkpoint)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from synth import make_batch
+
+pytestmark = pytest.mark.gpu
+CLASSES = ['Lumen']
+
+
+def _model(cuda, **kw):
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    kw.setdefault('compute_dtype', torch.float32)
+    return OCTSegmentationModel('unet', 'resnet18', 'unet_resnet18', 3, CLASSES, device=cuda, seed=5, **kw)
+
+
+def test_training_step_backward_matches_raw_step_and_oracle(cuda):
+    from oracle import DiceLoss, create_model
+    m = _model(cuda).train()
+    ref = create_model('unet', 'resnet18', classes=1).train()
+    ref.load_state_dict(m.model.state_dict())
+    img, mask = make_batch(2, 1, 64, seed=9)
+    out = m.training_step((img.to(cuda), mask.to(cuda)), 0)
+    assert m.model.arena.grad is None
+    (out['loss'] * 2.0).backward()          # Lightning calls loss.backward(); scaling must propagate
+    g_auto = m.model.arena.grad.clone()
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    loss_ref = DiceLoss()(ref((img - mean) / std), mask)
+    assert abs(out['loss'].item() - loss_ref.item()) < 1e-5
+    m2 = _model(cuda).train()
+    m2.model.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True, mean=m2._mean, std=m2._std, grad_scale=2.0)
+    torch.cuda.synchronize()
+    assert torch.allclose(g_auto, m2.model.arena.grad, rtol=1e-4, atol=1e-9)
+    met = m.training_step_outputs[-1]
+    assert set(met) == {'loss', 'iou', 'dice', 'recall', 'precision', 'f1'} and met['iou'].shape == (2, 1)
+
+
+@pytest.mark.parametrize('opt', ['Adam', 'RMSprop', 'SGD', 'RAdam'])
+def test_fused_optimizer_equals_torch_optimizer_on_the_arena(cuda, opt):
+    img, mask = make_batch(2, 1, 64, seed=9)
+    img, mask = img.to(cuda), mask.to(cuda)
+    ma = _model(cuda, optimizer_name=opt, lr=1e-3, weight_decay=1e-4, fused_optimizer=True).train()
+    mb = _model(cuda, optimizer_name=opt, lr=1e-3, weight_decay=1e-4, fused_optimizer=False).train()
+    oa, ob = ma.configure_optimizers(), mb.configure_optimizers()
+    for _ in range(3):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            m.training_step((img, mask), 0)['loss'].backward()
+            o.step()
+    torch.cuda.synchronize()
+    d = (ma.model.arena.data - mb.model.arena.data).abs().max().item()
+    assert d < 2e-5, d
+
+
+def test_checkpoint_roundtrip_and_predict(cuda, tmp_path):
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    from oracle import create_model
+    m = _model(cuda).eval()
+    sd = m.state_dict()
+    assert 'model.encoder.conv1.weight' in sd and 'mean' in sd and 'std' in sd
+    assert 'model.decoder.blocks.0.conv1.1.num_batches_tracked' in sd
+    path = os.path.join(tmp_path, 'weights.ckpt')
+    m.save_checkpoint(path)
+    m2 = OCTSegmentationModel.load_from_checkpoint(checkpoint_path=path, encoder_weights=None, arch='unet',
+                                                   encoder_name='resnet18', model_name='x', in_channels=3, classes=CLASSES,
+                                                   map_location='cuda:0', compute_dtype=torch.float32).eval()
+    assert torch.equal(m.model.arena.data, m2.model.arena.data)
+    # predict(): NHWC numpy in, no normalisation, {0,1} NHWC out -- against the oracle
+    ref = create_model('unet', 'resnet18', classes=1).eval()
+    ref.load_state_dict(m.model.state_dict())
+    img, _ = make_batch(3, 1, 64, seed=2)
+    x = img.permute(0, 2, 3, 1).numpy()
+    y = m2.predict(images=x, device='cuda')
+    with torch.no_grad():
+        z = ref(img)
+    y_ref = (z.sigmoid() > 0.5).float().permute(0, 2, 3, 1).numpy()
+    assert y.shape == (3, 64, 64, 1) and set(np.unique(y)) <= {0.0, 1.0}
+    unsure = (z.abs() < 1e-3).permute(0, 2, 3, 1).numpy()
+    assert np.all((y == y_ref) | unsure)
+    with pytest.raises(RuntimeError, match='divisible by 32'):
+        m2.predict(images=np.zeros((1, 50, 50, 3), np.float32), device='cuda')
+
+
+def test_segment_ensemble_channel_mapping(cuda, tmp_path):
+    from PIL import Image
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    from oct_segmentation_amd.predict import segment
+    specs = {'LM': ('unet', ['Lumen']), 'FC_LC': ('linknet', ['Lipid core', 'Fibrous cap']), 'VV': ('unet', ['Vasa vasorum'])}
+    for d, (arch, classes) in specs.items():
+        os.makedirs(os.path.join(tmp_path, d))
+        m = OCTSegmentationModel(arch, 'resnet18', f'{arch}_resnet18', 3, classes, device=cuda, seed=hash(d) % 100,
+                                 compute_dtype=torch.float32)
+        m.save_checkpoint(os.path.join(tmp_path, d, 'weights.ckpt'))
+        with open(os.path.join(tmp_path, d, 'config.json'), 'w') as f:
+            json.dump({'model_name': f'{arch}_resnet18', 'architecture': arch, 'encoder': 'resnet18', 'input_size': 64,
+                       'classes': classes}, f)
+    rng = np.random.default_rng(0)
+    images = [Image.fromarray(rng.integers(0, 255, (80, 80, 3), dtype=np.uint8)) for _ in range(3)]
+    masks = [np.zeros((96, 96, 4)) for _ in images]
+    out = segment(images, masks, [96, 96], ['Lumen', 'Fibrous cap', 'Lipid core', 'Vasa vasorum'], str(tmp_path),
+                  device='cuda', compute_dtype=torch.float32)
+    assert len(out) == 3 and out[0].shape == (96, 96, 4) and set(np.unique(out[0])) <= {0.0, 1.0}
+    # FC_LC: channel 0 = Lipid core -> mask channel 2, channel 1 = Fibrous cap -> mask channel 1
+    from oct_segmentation_amd.predict import load_model, preprocessing_img
+    model, cfg = load_model(os.path.join(tmp_path, 'FC_LC'), 'cuda', torch.float32)
+    p = model.predict(np.array([preprocessing_img(images[0], 64)]), 'cuda')[0]
+    lc = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
+    fc = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
+    assert np.array_equal(out[0][:, :, 2], lc) and np.array_equal(out[0][:, :, 1], fc)
