@@ -37,7 +37,8 @@ def test_training_step_backward_matches_raw_step_and_oracle(cuda):
     m2 = _model(cuda).train()
     m2.model.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True, mean=m2._mean, std=m2._std, grad_scale=2.0)
     torch.cuda.synchronize()
-    assert torch.allclose(g_auto, m2.model.arena.grad, rtol=1e-4, atol=1e-9)
+    # same engine both ways; only the fp32 atomics order of the split-K weight gradients differs
+    assert (g_auto - m2.model.arena.grad).abs().max().item() <= 1e-5 * g_auto.abs().max().item()
     met = m.training_step_outputs[-1]
     assert set(met) == {'loss', 'iou', 'dice', 'recall', 'precision', 'f1'} and met['iou'].shape == (2, 1)
 
@@ -50,10 +51,14 @@ def test_fused_optimizer_equals_torch_optimizer_on_the_arena(cuda, opt):
     mb = _model(cuda, optimizer_name=opt, lr=1e-3, weight_decay=1e-4, fused_optimizer=False).train()
     oa, ob = ma.configure_optimizers(), mb.configure_optimizers()
     for _ in range(3):
-        for m, o in ((ma, oa), (mb, ob)):
-            o.zero_grad()
-            m.training_step((img, mask), 0)['loss'].backward()
-            o.step()
+        # identical gradients for both (two backward runs differ in the last bits through the split-K
+        # atomics order, and Adam-type updates turn a sign flip of a ~0 gradient into a +-lr step)
+        oa.zero_grad()
+        ma.model.arena.data.copy_(mb.model.arena.data)
+        ma.training_step((img, mask), 0)['loss'].backward()
+        mb.model.arena.grad = ma.model.arena.grad.clone()
+        oa.step()
+        ob.step()
     torch.cuda.synchronize()
     d = (ma.model.arena.data - mb.model.arena.data).abs().max().item()
     assert d < 2e-5, d
