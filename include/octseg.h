@@ -121,6 +121,10 @@ int octseg_optim_step(int kind, float* params, const float* grads, float* state_
                       size_t numel, float lr, float weight_decay, int step, float grad_scale,
                       void* stream);
 
+/* diagnostic hook: with a library built with -DOCTSEG_STAMP, octseg_conv2d_forward adds per-phase cycle
+ * sums of the tap loop into dev_buf[6] (u64, device); a no-op in the shipped build. */
+int octseg_debug_set_stamp(unsigned long long* dev_buf);
+
 /* ---- single-op entry points (NHWC device tensors of `dtype`; weights fp32 in arena layout) ---- */
 /* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w[R][S][Cout][Cin]) (+bias);  transposed=1: ConvTranspose2d
  * 4x4 s2 p1 with w[R][S][Cout][Cin].  scratch: device bytes >= octseg_conv2d_scratch_bytes(). */

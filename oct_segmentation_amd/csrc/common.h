@@ -59,6 +59,7 @@ struct ConvArgs {
   const float* bias;      // per-Cout, nullable
   float* stat_slab;       // nullable: [slab rows][Cout][2] partial (sum, sumsq) per M tile
   int slab_row0;
+  unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only: per-phase cycle sums, else nullptr
 };
 
 struct WgradArgs {

@@ -149,6 +149,28 @@ struct WindowStager {
   float sc[VEC], sh[VEC];
   bool cvalid, has_aff;
   int cv, p0;
+  const char* img_base;   // source pointer of (image n, this thread's channel vector): set by bind_image()
+  int row_bytes, pix_bytes;
+  __device__ __forceinline__ void bind_image(int n) {
+    img_base = s.ptr + ((size_t)n * s.H * s.W * s.C + s.cl) * sizeof(T);
+    pix_bytes = s.C * (int)sizeof(T);
+    row_bytes = s.W * pix_bytes;
+  }
+  // load of window pixel (hy, hx) (already decomposed by the caller: no division in the pipeline);
+  // 32-bit offset inside the image, clamped address, validity resolved at write time
+  __device__ __forceinline__ uint4 load_at(int hy, int hx, bool in_window, int gy0, int gx0, int smul, int IH, int IW,
+                                           bool& ok) const {
+    const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
+    ok = cvalid && in_window && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    const int iyc = min(max(iy, 0), IH - 1), ixc = min(max(ix, 0), IW - 1);
+    const unsigned off = (unsigned)((iyc >> s.up) * row_bytes + (ixc >> s.up) * pix_bytes);
+    return *(const uint4*)(img_base + off);
+  }
+  __device__ __forceinline__ void write_at(char* lds_row, uint4 v, bool ok) const {
+    if (has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    *(uint4*)(lds_row + cv * 16) = v;
+  }
   __device__ __forceinline__ void setup(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid) {
     cv = tid % VPR;
     p0 = tid / VPR;

@@ -881,6 +881,10 @@ static bool geom_ok(int dtype, int Cin, int Cout, int R, int S, int stride, int 
   if (transposed && !(R == 4 && stride == 2)) return false;
   return true;
 }
+static unsigned long long* g_stamp = nullptr;
+// diagnostic builds only (-DOCTSEG_STAMP): device buffer of 6 u64 receiving the per-phase cycle sums
+int octseg_debug_set_stamp(unsigned long long* dev_buf) { g_stamp = dev_buf; return OCTSEG_OK; }
+
 static Geom op_geom(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int transposed) {
   Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
   if (transposed) { g.OH = H * 2; g.OW = W * 2; } else { g.OH = (H + 2 * pad - R) / stride + 1; g.OW = (W + 2 * pad - S) / stride + 1; }
@@ -908,7 +912,7 @@ int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float*
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.W = scratch; a.bias = bias;
     DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW;
-    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr;
+    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr; a.stamp = g_stamp;
     HIPCHK(launch_conv(dtype, a, st));
   }
   return OCTSEG_OK;

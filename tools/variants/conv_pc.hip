@@ -39,26 +39,29 @@ namespace octseg {
 template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS = RB / 32, VPR = RB / 16; };
 
 template <typename T, int NT, int WN, int WM, int RB>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a, const int dbuf) {
+__global__ __launch_bounds__(64 * (WM * WN + (WM * WN >= 4 ? WM * WN / 2 : 2))) void conv_mfma_kernel(const ConvArgs a, const int dbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NTHREADS = 64 * WM * WN;
+  constexpr int NC = WM * WN;                 // consumer waves: ds_read + MFMA only
+  constexpr int NP = NC >= 4 ? NC / 2 : 2;    // producer waves: address math, loads, LDS-DMA, BN affine, LDS stores
+  constexpr int NG = NP / 2;                  // ... in two groups that alternate (issue for it+2 | finish it+1)
+  constexpr int NTHREADS = 64 * (NC + NP);
+  constexpr int NPT = 64 * NG;                // threads of one producer group
   constexpr int BN = NT * 32 * WN;
   constexpr int TH = 4 * WM;
   constexpr int BM = TH * TW;
   constexpr int VEC = Tr<T>::VEC;
   constexpr int KC = RB / (int)sizeof(T);
   constexpr int PITCH = ConvCfg<RB>::PITCH, KSTEPS = ConvCfg<RB>::KSTEPS, VPR = ConvCfg<RB>::VPR;
-  constexpr int NWAVES = WM * WN;
   constexpr int BBYTES = BN * RB;                             // one weight slab = its packed image
   constexpr int NDMA = BBYTES / 1024;                         // 1 KiB LDS-DMA pieces per slab
-  constexpr int DPW = (NDMA + NWAVES - 1) / NWAVES;           // pieces issued per wave
+  constexpr int DPW = (NDMA + NC - 1) / NC;                   // pieces issued per consumer wave (LDS-DMA rate is per wave)
   constexpr int SWZ_DIV = 256 / RB;                           // rows per 256-byte LDS bank line
-  constexpr int MAXP = 4;                                     // window passes prefetched per tap
-  typedef WindowStager<T, RB, NTHREADS> Stager;
+  constexpr int PMAX = 16;                                    // window vectors a producer thread keeps in flight
+  typedef WindowStager<T, RB, NPT> Stager;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < NC;
 
   const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
@@ -88,20 +91,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   const int w_mt = n * tiles_x * tiles_y + mt_idx;   // M-tile index (BN-stat slab row)
 
   // window geometry
-  const bool single = a.ntaps == 1;
+  const int ntaps = a.ntaps;
+  const bool single = ntaps == 1;
   const int lstride = single ? 1 : a.istride;   // LDS lookup stride
   const int smul = single ? a.istride : 1;      // staging coordinate multiplier
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
-  const int npass = (npix + Stager::PSTEP - 1) / Stager::PSTEP;
+  const int npass = (npix + Stager::PSTEP - 1) / Stager::PSTEP;   // producer passes covering the window
   const float inv_rw = 1.0f / (float)RW;
   const int gy0 = y0 * a.istride + a.min_dy, gx0 = x0 * a.istride + a.min_dx;
+  const int IHl = a.IH, IWl = a.IW;
 
-  const int abytes = npass * Stager::PSTEP * PITCH;   // rows padded to whole passes (unconditional stores)
+  const int abytes = npass * Stager::PSTEP * PITCH;   // rows padded to whole passes
   char* ldsA = smem;                                  // [1 or 2] windows
-  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slab ring
+  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [4] weight slab ring
+  const int nchunks = (a.Cin + KC - 1) / KC;
+  const int niter = nchunks * ntaps;
 
+  // tap tables in VGPR lanes (lane i = tap i), fetched per iteration with v_readlane: a kernarg s_load in
+  // the loop costs its full scalar-cache latency every iteration
+  int v_toff = 0, v_tapw = 0;
+  if (lane < ntaps) {
+    v_toff = single ? 0 : ((a.tap_dy[lane] - a.min_dy) * RW + (a.tap_dx[lane] - a.min_dx)) * PITCH;
+    v_tapw = a.tap_w[lane];
+  }
+
+#ifdef OCTSEG_STAMP
+  unsigned long long ts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   f32x16_t acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -109,194 +127,216 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+  const int wm = consumer ? wave / WN : 0, wn = consumer ? wave % WN : 0;
+  const int r = lane & 31, h = lane >> 5;
 
-  int abase[2], bbase[NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int ty = wm * 4 + mt * 2 + (r >> 4), tx = r & 15;
-    abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
-  }
-  int bswz[NT];  // XOR swizzle of the 16-byte chunk index inside a slab row (matches pack_weight_image)
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int row = wn * NT * 32 + nt * 32 + r;
-    bbase[nt] = row * RB;
-    bswz[nt] = (row / SWZ_DIV) & (VPR - 1);
-  }
-
-  const int nchunks = (a.Cin + KC - 1) / KC;
+  // LDS-DMA of a packed weight slab into ring slot `slot`, issued by the consumer waves (DPW pieces of 1 KiB
+  // each; the DMA rate is per issuing wave, so the slab is spread over all of them) through inline asm: a
+  // builtin LDS-DMA makes hipcc drain vmcnt(0) before later ds accesses it cannot prove disjoint.
   const char* Wp = (const char*)a.W;
-
-  const int ntiles_n = gridDim.y;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned ldsB_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsB;  // LDS byte address
-  // LDS-DMA of a packed slab into ring slot `slot`.  Issued through inline asm: hipcc cannot prove that
-  // a builtin LDS-DMA write does not alias the ds_reads that follow (runtime ring offsets) and would drain
-  // vmcnt(0) right behind it; the asm form is invisible to its waitcnt pass and is retired by the explicit
-  // s_waitcnt in front of the barrier instead.  Per-lane source = precomputed base + scalar slab offset.
-  const char* dma_src0 = Wp + (size_t)nt_idx * BBYTES + (size_t)wave_u * DPW * 1024 + lane * 16;
-  const size_t slab_stride = (size_t)ntiles_n * BBYTES;  // between consecutive (tap, chunk) slabs
-  const bool dma_wave = NDMA % NWAVES == 0 || wave_u * DPW < NDMA;
-  auto dmaB = [&](int slab_idx, int slot) {   // slab_idx = tapw * nchunks + chunk
+  const char* dma_src0 = Wp + (size_t)nt_idx * BBYTES + (size_t)wave * DPW * 1024 + lane * 16;
+  const size_t slab_stride = (size_t)gridDim.y * BBYTES;   // between consecutive (tap, chunk) slabs
+  const bool dma_wave = consumer && (NDMA % NC == 0 || wave * DPW < NDMA);
+  auto dmaB = [&](int slab_idx, int slot) {                // slab_idx = tapw * nchunks + chunk
     if (dma_wave) {
       const char* gsrc0 = dma_src0 + (size_t)slab_idx * slab_stride;
 #pragma unroll
       for (int j = 0; j < DPW; ++j) {
         const char* gsrc = gsrc0 + j * 1024;
-        const unsigned dst = ldsB_addr + slot * BBYTES + (wave_u * DPW + j) * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ldsB_addr + slot * BBYTES + (wave * DPW + j) * 1024);
         unsigned keep;
+#ifndef OCTSEG_NODMA
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#else
+        (void)gsrc; (void)dst; keep = 0; (void)keep;
+#endif
       }
     }
   };
-  // tap tables in VGPR lanes (lane i = tap i), fetched per iteration with v_readlane: a kernarg s_load in
-  // the loop costs its full scalar-cache latency every iteration
-  int v_toff = 0, v_tapw = 0;
-  if (lane < a.ntaps) {
-    v_toff = single ? 0 : ((a.tap_dy[lane] - a.min_dy) * RW + (a.tap_dx[lane] - a.min_dx)) * PITCH;
-    v_tapw = a.tap_w[lane];
-  }
-  auto stage_full = [&](const Stager& sg, char* dst) {
-    for (int p = 0; p < npass; p += MAXP) {
-      uint4 v[MAXP];
-      bool ok[MAXP];
-#pragma unroll
-      for (int u = 0; u < MAXP; ++u) v[u] = sg.load(min(p + u, npass - 1), n, gy0, gx0, smul, RW, npix, inv_rw, a.IH, a.IW, ok[u]);
-#pragma unroll
-      for (int u = 0; u < MAXP; ++u) sg.write(dst, min(p + u, npass - 1), v[u], ok[u]);
-    }
-  };
-  // MFMAs of one tap.  The LDS fragment reads run two k-steps ahead of the MFMAs that consume them
-  // (three register sets): LDS latency under load is several hundred cycles, a k-step of MFMAs is ~128.
-  auto mma_tap = [&](const char* awin, const char* bsl, int toff) {
-    uint4 af[3][2], bf[3][NT];
-    auto frag_load = [&](int buf, int ks) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
-    };
-    frag_load(0, 0);
-    if (KSTEPS > 1) frag_load(1, 1);
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
-      // pin the stage order: left alone, hipcc sinks every read next to its MFMA (lgkmcnt(1) in front of
-      // almost every MFMA pair) and the LDS latency is paid k-step by k-step
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  // slab index of iteration k (clamped: past the end the last slab is fetched again into a free slot, which
+  // keeps the number of outstanding DMAs per wave constant for the counted s_waitcnt below)
+  auto slab_of = [&](int k) {
+    k = min(k, niter - 1);
+    const int kc = k / ntaps, kt = k - kc * ntaps;
+    return __builtin_amdgcn_readlane(v_tapw, kt) * nchunks + kc;
   };
 
-  // ---------------- prologue: window of chunk 0 + first weight slab ----------------
-  {
-    Stager cur;
-    cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
-    dmaB(a.tap_w[0] * nchunks, 0);
-    stage_full(cur, ldsA);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---------------- main loop ----------------
-  // PPT = window passes of the NEXT chunk prefetched per tap (1 for multi-tap convs, 4 for 1x1);
-  // every load and every LDS store of the pipeline is unconditional: indices are clamped instead
-  // (re-staging the last pass / the last chunk again is harmless).
-#ifdef OCTSEG_STAMP
-  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
-#endif
-  const int IHl = a.IH, IWl = a.IW, ntaps = a.ntaps;
-  // window-pixel cursor of the prefetch: pass p covers pixels p*PSTEP + p0; advancing by one pass is
-  // (hy, hx) += (PSTEP / RW, PSTEP % RW) with one carry -- no division in the loop
-  const int p0w = tid / VPR;
-  const int hy_first = (int)(((float)p0w + 0.5f) * inv_rw), hx_first = p0w - hy_first * RW;
-  const int dq = Stager::PSTEP / RW, dr = Stager::PSTEP - dq * RW;
-  auto run = [&](auto ppt_c, auto dbuf_c) {
-    constexpr int PPT = decltype(ppt_c)::value;
-    constexpr bool DBUF = decltype(dbuf_c)::value;
-    int it = 0;
-    int tap2 = ntaps == 1 ? 0 : 1, chunk2 = ntaps == 1 ? min(1, nchunks - 1) : 0;  // slab of iteration 1
+  if (consumer) {
+    // =========================== consumer waves: fragments + MFMA ===========================
+    int abase[2], bbase[NT], bswz[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int ty = wm * 4 + mt * 2 + (r >> 4), tx = r & 15;
+      abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wn * NT * 32 + nt * 32 + r;
+      bbase[nt] = row * RB;
+      bswz[nt] = (row / SWZ_DIV) & (VPR - 1);   // XOR swizzle of the 16-byte chunk index (matches pack_weight_image)
+    }
+    dmaB(slab_of(0), 0);
+    dmaB(slab_of(1), 1);
+    dmaB(slab_of(2), 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");   // slab 0 landed
+    __builtin_amdgcn_s_barrier();               // ... and the first window staged by the producers
+    asm volatile("" ::: "memory");
+    int slot = 0, it = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-      const bool has_next = chunk + 1 < nchunks;
-      Stager nxt;
-      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid);
-      nxt.bind_image(n);
-      const char* awin = ldsA + ((DBUF && (chunk & 1)) ? abytes : 0);
-      char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
-      int hy = hy_first, hx = hx_first, hp = p0w;      // cursor of the pass to prefetch next
-      char* wrow = anext + p0w * PITCH;
+      const char* awin = ldsA + ((dbuf && (chunk & 1)) ? abytes : 0);
       for (int t = 0; t < ntaps; ++t, ++it) {
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-        (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5;
-        STAMP(s0);
-        // window slice of the next chunk (register load) and the LDS-DMA of the next iteration's slab:
-        // both fly under the MFMAs below and are retired in front of the barrier.
-        uint4 av[PPT];
-        bool aok[PPT];
-        char* wr[PPT];
-        if constexpr (DBUF) {
-#pragma unroll
-          for (int u = 0; u < PPT; ++u) {
-            av[u] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[u]);
-            wr[u] = wrow;
-            // advance to the next pass unless this was the last one (then it is simply staged again)
-            const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
-            if (adv) {
-              hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
-              hy += dq; hx += dr;
-              if (hx >= RW) { hx -= RW; hy += 1; }
-            }
-          }
-        }
-        dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, (it + 1) & 1);
+        unsigned long long c0 = 0, c1 = 0, c2 = 0; (void)c0; (void)c1; (void)c2;
+        STAMP(c0);
+        dmaB(slab_of(it + 3), (slot + 3) & 3);   // three iterations ahead; its slot was last read in iteration it-1
         const int toff = __builtin_amdgcn_readlane(v_toff, t);
-        STAMP(s1);
-        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
-        STAMP(s2);
-        // keep the consumers of the prefetched registers (BN affine, LDS stores) behind the MFMA block
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBUF) {
+        const char* bsl = ldsB + slot * BBYTES;
+        slot = (slot + 1) & 3;
+        // fragment reads run two k-steps ahead of the MFMAs that consume them (three register sets)
+        uint4 af[3][2], bf[3][NT];
+        auto frag_load = [&](int buf, int ks) {
 #pragma unroll
-          for (int u = 0; u < PPT; ++u) nxt.write_at(wr[u], av[u], aok[u]);
+          for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
+        };
+        frag_load(0, 0);
+        if (KSTEPS > 1) frag_load(1, 1);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        STAMP(s3);
-        // the slab of iteration it+1 (and this wave's LDS stores) must have landed before anyone passes
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(c1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");   // slab of iteration it+1 landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        STAMP(s4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        STAMP(s5);
+        STAMP(c2);
 #ifdef OCTSEG_STAMP
-        tsum[0] += s1 - s0; tsum[1] += s2 - s1; tsum[2] += s3 - s2; tsum[3] += s4 - s3; tsum[4] += s5 - s4; tsum[5] += 1;
+        ts[0] += c1 - c0; ts[1] += c2 - c1; ts[2] += 1;
 #endif
-        // (tap, chunk) cursor of the next iteration's slab (clamped at the very end)
-        if (++tap2 == ntaps) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
       }
-      if constexpr (!DBUF) {
-        if (has_next) {  // window does not fit twice: restage in place (all waves passed the barrier)
-          stage_full(nxt, ldsA);
-          __syncthreads();
-        }
+      if (!dbuf && chunk + 1 < nchunks) {  // producers restage the single window between these two barriers
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
     }
-  };
-  if (dbuf) {
-    if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
-    else run(std::integral_constant<int, 1>{}, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail DMAs must not land in the epilogue's LDS tile
   } else {
-    run(std::integral_constant<int, 1>{}, std::false_type{});
-  }
+    // =========================== producer waves: everything that moves data ===========================
+    // Two groups take turns: in iteration j the group ((j+1) & 1) FINISHes iteration j+1 (s_waitcnt vmcnt(0)
+    // on what it issued on its previous turn, BN affine, LDS stores) and then ISSUEs the loads of iteration
+    // j+3 (LDS-DMA of the weight slab into ring slot (j+3) & 3, window-slice vectors into registers).  Every
+    // load so gets two full iterations to land (memory latency under load is ~2500 cycles, an iteration
+    // ~1100), and a wave only ever waits for ALL of its own outstanding loads -- no counted vmcnt.
+    // producers are the youngest waves of the workgroup and would lose every issue-arbitration round to the
+    // MFMA-heavy consumers (priority, then age): give them static priority
+    __builtin_amdgcn_s_setprio(3);
+    const int pw = wave - NC;
+    const int grp = pw / NG;                       // producer group
+    const int gtid = tid - (NC + grp * NG) * 64;    // thread inside the group
+    const int ppt = (npass + ntaps - 1) / ntaps;        // window passes (of a group) per slice, <= PMAX (host check)
+    Stager sg;                                          // stager of the chunk this group is currently filling
+    int sg_chunk = -1;
+    uint4 uv[PMAX];
+    bool uok[PMAX];
+    int u_first = 0, u_cnt = 0;                         // passes held in uv[]
+    char* u_dst = ldsA;
+    // iteration k needs: slab(k) and, before its chunk starts, the whole window of chunk(k).  Slice s of the
+    // window of chunk c+1 is finished during iteration (c, s), i.e. it belongs to "k = c * ntaps + s + 1".
+    auto issue = [&](int k) {          // loads for iteration k (k >= 1)
+      const int pc = (k - 1) / ntaps, ps = (k - 1) - pc * ntaps;   // slice ps of the window of chunk pc + 1
+      u_cnt = 0;
+      if (dbuf && pc + 1 < nchunks && k <= niter) {
+        unsigned long long q0 = 0, q1 = 0; (void)q0; (void)q1;
+        STAMP(q0);
+        if (sg_chunk != pc + 1) { sg.setup(a.src, a.nsrc, a.Cin, pc + 1, gtid); sg.bind_image(n); sg_chunk = pc + 1; }
+        STAMP(q1);
+#ifdef OCTSEG_STAMP
+        ts[7] += q1 - q0;
+#endif
+        u_first = ps * ppt;
+        u_cnt = min(ppt, npass - u_first);
+        u_dst = ldsA + (((pc + 1) & 1) ? abytes : 0);
+#pragma unroll
+        for (int u = 0; u < PMAX; ++u)
+          if (u < u_cnt) {
+            const int hp = (u_first + u) * Stager::PSTEP + sg.p0;
+            const int hy = (int)(((float)hp + 0.5f) * inv_rw), hx = hp - hy * RW;
+#ifndef OCTSEG_NOALOAD
+            uv[u] = sg.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, uok[u]);
+#else
+            uv[u] = make_uint4(hy, hx, 0, 0); uok[u] = true;
+#endif
+          }
+      }
+    };
+    auto finish = [&]() {              // retire what this group issued one iteration ago
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u)
+        if (u < u_cnt) sg.write_at(u_dst + ((u_first + u) * Stager::PSTEP + sg.p0) * PITCH, uv[u], uok[u]);
+      u_cnt = 0;
+    };
+    // synchronous staging of a whole window by this group's threads (prologue / single-buffer restage)
+    auto stage_window_now = [&](int chunk, char* dst, int p_begin, int p_step) {
+      Stager cur;
+      cur.setup(a.src, a.nsrc, a.Cin, chunk, gtid);
+      cur.bind_image(n);
+      for (int p = p_begin; p < npass; p += p_step) {
+        const int hp = p * Stager::PSTEP + cur.p0;
+        const int hy = (int)(((float)hp + 0.5f) * inv_rw), hx = hp - hy * RW;
+        bool ok;
+        const uint4 v = cur.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok);
+        cur.write_at(dst + hp * PITCH, v, ok);
+      }
+    };
+    // ---- prologue: window of chunk 0 (both groups, interleaved passes) + slab 0; group 1 then issues iteration 1
+    stage_window_now(0, ldsA, grp, 2);
+    if (grp == 1) issue(1); else issue(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int j = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      for (int t = 0; t < ntaps; ++t, ++j) {
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0; (void)p0; (void)p1; (void)p2; (void)p3;
+        const bool act = ((j + 1) & 1) == grp;
+        STAMP(p0);
+        if (act) finish();
+        STAMP(p1);
+        if (act) issue(j + 3);
+        STAMP(p2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STAMP(p3);
+#ifdef OCTSEG_STAMP
+        if (act) { ts[3] += p1 - p0; ts[4] += p2 - p1; ts[5] += p3 - p2; ts[6] += 1; }
 
+#endif
+      }
+      if (!dbuf && chunk + 1 < nchunks) {   // the window does not fit twice: restage in place while the consumers wait
+        stage_window_now(chunk + 1, ldsA, grp, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave may still be landing in LDS
+  }
 #ifdef OCTSEG_STAMP
   if (a.stamp != nullptr && lane == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
+    for (int i = 0; i < 9; ++i) atomicAdd(a.stamp + i, ts[i]);
 #endif
+  __syncthreads();
 
   // ---------------- epilogue ----------------
   // (all waves are past the last barrier: LDS is free)
@@ -305,49 +345,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   char* otile = smem;                                    // [BM][BN] T
   float* red = (float*)(smem + BM * OPITCH);             // [WM][BN][2] stat partials
   const bool head = a.out_mode == OUT_HEAD_NCHW;
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    s1[nt] = 0.f; s2[nt] = 0.f;
-    const int cl = wn * NT * 32 + nt * 32 + r;
-    const int co = co0 + cl;
-    const bool cok = co < a.Cout;
-    const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int p = mt * 32 + rr;                       // pixel inside the wave's 64
-        const int ty = wm * 4 + (p >> 4), tx = p & 15;
-        const int gy = y0 + ty, gx = x0 + tx;
-        const float val = acc[mt][nt][i] + bias;
-        if (cok && gy < a.OH && gx < a.OW) {
-          s1[nt] += val; s2[nt] += val * val;
-          if (head) {
-            const DstDesc& d = a.dst[0];
-            const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
-            ((float*)d.ptr)[(((size_t)n * a.Cout + co) * d.H + oy) * d.W + ox] = val;
+  if (consumer) {
+    float s1[NT], s2[NT];
+  #pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      s1[nt] = 0.f; s2[nt] = 0.f;
+      const int cl = wn * NT * 32 + nt * 32 + r;
+      const int co = co0 + cl;
+      const bool cok = co < a.Cout;
+      const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+  #pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+  #pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int p = mt * 32 + rr;                       // pixel inside the wave's 64
+          const int ty = wm * 4 + (p >> 4), tx = p & 15;
+          const int gy = y0 + ty, gx = x0 + tx;
+          const float val = acc[mt][nt][i] + bias;
+          if (cok && gy < a.OH && gx < a.OW) {
+            s1[nt] += val; s2[nt] += val * val;
+            if (head) {
+              const DstDesc& d = a.dst[0];
+              const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
+              ((float*)d.ptr)[(((size_t)n * a.Cout + co) * d.H + oy) * d.W + ox] = val;
+            }
+          }
+          if (!head) {
+            if (sizeof(T) == 4) *(float*)(otile + (ty * TW + tx) * OPITCH + cl * 4) = val;
+            else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = __builtin_bit_cast(unsigned short, b); }
           }
         }
-        if (!head) {
-          if (sizeof(T) == 4) *(float*)(otile + (ty * TW + tx) * OPITCH + cl * 4) = val;
-          else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = __builtin_bit_cast(unsigned short, b); }
+      }
+    }
+    if (a.stat_slab != nullptr) {
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+        if (h == 0) {
+          const int cl = wn * NT * 32 + nt * 32 + r;
+          red[(wm * BN + cl) * 2 + 0] = s1[nt];
+          red[(wm * BN + cl) * 2 + 1] = s2[nt];
         }
       }
     }
-  }
-  if (a.stat_slab != nullptr) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      s1[nt] += __shfl_xor(s1[nt], 32);
-      s2[nt] += __shfl_xor(s2[nt], 32);
-      if (h == 0) {
-        const int cl = wn * NT * 32 + nt * 32 + r;
-        red[(wm * BN + cl) * 2 + 0] = s1[nt];
-        red[(wm * BN + cl) * 2 + 1] = s2[nt];
-      }
-    }
+
   }
   __syncthreads();
   if (a.stat_slab != nullptr && tid < BN) {
@@ -413,12 +456,13 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
-  const int nthreads = 64 * v.WM * v.WN;
+  const int nc = v.WM * v.WN, np = nc >= 4 ? nc / 2 : 2;
+  const int nthreads = 64 * (np / 2);             // threads of one producer group
   const int pstep = nthreads / (v.RB / 16);
   if (npass_out) *npass_out = (npix + pstep - 1) / pstep;
   const int npass = (npix + pstep - 1) / pstep;
   const size_t abytes = (size_t)npass * pstep * PITCH;
-  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 2 * (size_t)BN * v.RB;
+  const size_t main_loop = (dbuf ? 2 : 1) * abytes + 4 * (size_t)BN * v.RB;
   const size_t epi = (size_t)BM * (BN * esz + 16) + (size_t)v.WM * BN * 2 * sizeof(float);
   return main_loop > epi ? main_loop : epi;
 }
@@ -435,7 +479,7 @@ hipError_t launch_variant(const ConvArgs& a, int dbuf, size_t lds, hipStream_t s
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<T, NT, WN, WM, RB>), grid, dim3(64 * WM * WN), lds, st, a, dbuf);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, NT, WN, WM, RB>), grid, dim3(64 * (WM * WN + (WM * WN >= 4 ? WM * WN / 2 : 2))), lds, st, a, dbuf);
   return hipGetLastError();
 }
 
@@ -461,9 +505,9 @@ Choice choose(const ConvArgs& a, int esz) {
       Variant v{NT, WN, order[k], RB};
       int npass = 0;
       const size_t lds = variant_lds(a, v, esz, pref_dbuf, &npass);
-      // the pipeline prefetches 1 pass per tap (4 for 1x1): the next window must fit that budget
-      const bool fits_pipe = a.ntaps == 1 ? npass <= 4 : npass <= a.ntaps;
-      if (lds <= cap && (!pref_dbuf || fits_pipe)) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
+      // a window slice (passes per tap) must fit the producer's register set (PMAX = 16 vectors)
+      const bool fits_regs = !pref_dbuf || (npass + a.ntaps - 1) / a.ntaps <= 16;
+      if (lds <= cap && fits_regs) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
     }
   c.v = Variant{NT, WN, 2, RB}; c.dbuf = 0; c.lds = variant_lds(a, c.v, esz, 0, nullptr);
   return c;
