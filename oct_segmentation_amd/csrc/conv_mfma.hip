@@ -456,7 +456,9 @@ Choice choose(const ConvArgs& a, int esz) {
   const size_t cap = 160 * 1024;
   const int wm_first = util(8) > 1.15 * util(16) ? 2 : 4;
   const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};
-  for (int pref_dbuf = 1; pref_dbuf >= 0; --pref_dbuf)
+  const int nchunks_c = (a.Cin + RB / esz - 1) / (RB / esz);
+  // a single K chunk never restages its window: a second buffer would only cost occupancy
+  for (int pref_dbuf = nchunks_c > 1 ? 1 : 0; pref_dbuf >= 0; --pref_dbuf)
     for (int k = 0; k < 2; ++k) {
       Variant v{NT, WN, order[k], RB};
       int npass = 0;
@@ -512,8 +514,34 @@ int conv_num_mtiles(const ConvArgs& a, int dtype) {
   return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
 }
 
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
-  if (a.ntaps <= 0) return hipSuccess;
+// A stride-1 1x1 convolution does not care about image geometry: present the N*H*W pixels as one image of
+// 16-pixel rows so that every tile is full (a 22x22 map otherwise fills 47 % of its 16x16 tiles).
+static bool flatten_1x1(ConvArgs& a) {
+  if (a.ntaps != 1 || a.istride != 1 || a.ostride != 1 || a.out_mode == OUT_HEAD_NCHW) return false;
+  if (a.tap_dy[0] != 0 || a.tap_dx[0] != 0) return false;
+  const long long npix = (long long)a.N * a.OH * a.OW;
+  if (npix % TW != 0 || a.IH != a.OH || a.IW != a.OW) return false;
+  for (int i = 0; i < a.nsrc; ++i)
+    if (a.src[i].up || a.src[i].H != a.IH || a.src[i].W != a.IW) return false;
+  for (int i = 0; i < a.ndst; ++i)
+    if (a.dst[i].H != a.OH || a.dst[i].W != a.OW) return false;
+  const int rows = (int)(npix / TW);
+  a.N = 1; a.IH = a.OH = rows; a.IW = a.OW = TW;
+  for (int i = 0; i < a.nsrc; ++i) { a.src[i].H = rows; a.src[i].W = TW; }
+  for (int i = 0; i < a.ndst; ++i) { a.dst[i].H = rows; a.dst[i].W = TW; }
+  return true;
+}
+
+int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
+  ConvArgs a = a0;
+  flatten_1x1(a);
+  return conv_num_mtiles(a, dtype);
+}
+
+hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
+  if (a0.ntaps <= 0) return hipSuccess;
+  ConvArgs a = a0;
+  flatten_1x1(a);
   if (dtype == DT_F32) return dispatch<float>(a, st);
   return dispatch<bf16_t>(a, st);
 }

@@ -5,7 +5,8 @@
 namespace octseg {
 
 // conv_mfma.hip
-int conv_num_mtiles(const ConvArgs& a, int dtype);  // M tiles (= BN-stat slab rows) of a launch
+int conv_num_mtiles(const ConvArgs& a, int dtype);       // M tiles of a launch as given
+int conv_num_mtiles_flat(const ConvArgs& a, int dtype);  // ... as launch_conv runs it (= BN-stat slab rows)
 // Layout of the packed weight image a launch expects in ConvArgs::W:
 // [wtap][chunk][N tile][BN rows][RB bytes], zero padded, 16-byte chunks XOR-swizzled per row.
 struct ConvPackInfo { int BN, RB, nchunks, ntiles; };

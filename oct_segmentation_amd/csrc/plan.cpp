@@ -434,7 +434,14 @@ static int build_plan(octseg_plan* P) {
     }
     if (L.bn >= 0) {
       int rows = 0;
-      for (auto& a : la) rows += conv_num_mtiles(a, P->dtype);
+      for (auto& a : la) {
+        // geometry-only descriptors, so that the tile count equals what run_forward will launch
+        a.nsrc = 0;
+        for (auto& s : L.srcs) { SrcDesc d{}; d.H = P->tensors[s.v.t].H; d.W = P->tensors[s.v.t].W; d.up = s.up; a.src[a.nsrc++] = d; }
+        DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; a.dst[0] = dd; a.ndst = 1;
+        a.out_mode = L.head ? OUT_HEAD_NCHW : OUT_STORE;
+        rows += conv_num_mtiles_flat(a, P->dtype);
+      }
       P->bns[L.bn].rows = rows;
       slab = std::max(slab, (size_t)rows * L.Cout * 2 * sizeof(float));
     }
@@ -541,7 +548,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.dst[0] = d;
           a.stat_slab = (L.bn >= 0 && E.train) ? (float*)(E.ws + P->slab_off) : nullptr;
           a.slab_row0 = row0;
-          row0 += conv_num_mtiles(a, P->dtype);
+          row0 += conv_num_mtiles_flat(a, P->dtype);
           ProfScope ps(0, 2.0 * layer_macs(L) / (double)la.size(), E.st, L.name);
           HIPCHK(launch_conv(P->dtype, a, E.st));
         }

@@ -257,8 +257,22 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
 }
 
 // Tap tables with other sizes are split host-side into groups the instantiations cover.
-hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
-  if (a.ntaps <= 0) return hipSuccess;
+// stride-1 1x1: the pixel list is geometry free -> one image of 16-pixel rows, every tile full
+static void flatten_1x1(WgradArgs& a) {
+  if (a.ntaps != 1 || a.istride != 1 || a.dstride != 1 || a.tap_dy[0] != 0 || a.tap_dx[0] != 0) return;
+  const long long npix = (long long)a.N * a.OH * a.OW;
+  if (npix % TW != 0 || a.IH != a.OH || a.IW != a.OW || a.DH != a.OH || a.DW != a.OW) return;
+  for (int i = 0; i < a.nsrc; ++i)
+    if (a.src[i].up || a.src[i].H != a.IH || a.src[i].W != a.IW) return;
+  const int rows = (int)(npix / TW);
+  a.N = 1; a.IH = a.OH = a.DH = rows; a.IW = a.OW = a.DW = TW;
+  for (int i = 0; i < a.nsrc; ++i) { a.src[i].H = rows; a.src[i].W = TW; }
+}
+
+hipError_t launch_wgrad(int dtype, const WgradArgs& a0, hipStream_t st) {
+  if (a0.ntaps <= 0) return hipSuccess;
+  WgradArgs a = a0;
+  flatten_1x1(a);
   if (a.ntaps == 1 || a.ntaps == 4 || a.ntaps == 9) {
     if (dtype == DT_F32) {
       if (a.ntaps == 1) return launch_wgrad_t<float, 1>(a, dtype, st);
