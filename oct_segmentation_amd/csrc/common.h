@@ -33,6 +33,7 @@ struct DstDesc {
   int c0;     // first output channel mapped to this destination
   int cn;     // number of channels
   int H, W;   // full spatial size of the destination tensor
+  int accum;  // 1: add to what is there (a later gradient contribution), 0: plain store (first writer)
 };
 
 enum OutMode { OUT_STORE = 0, OUT_ACCUM = 1, OUT_HEAD_NCHW = 2 };

@@ -368,16 +368,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       const int gy = y0 + ty, gx = x0 + tx;
       const int co = co0 + cvv * VEC;
       if (gy >= a.OH || gx >= a.OW || co >= a.Cout) continue;
-      char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W;
+      char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W, dacc = a.dst[0].accum;
 #pragma unroll
       for (int i = 1; i < MAX_SRC; ++i)
         if (i < a.ndst && co >= a.dst[i].c0) {
-          dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W;
+          dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W; dacc = a.dst[i].accum;
         }
       const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
       uint4* gp = (uint4*)(dptr + ((((size_t)n * dH + oy) * dW + ox) * dC + (co - dc0)) * sizeof(T));
       uint4 val = *(const uint4*)(otile + p * OPITCH + cvv * 16);
-      if (a.out_mode == OUT_ACCUM) {
+      if (a.out_mode == OUT_ACCUM || dacc) {
         const uint4 old = *gp;
         if (sizeof(T) == 4) {
           val.x = __float_as_uint(__uint_as_float(val.x) + __uint_as_float(old.x));

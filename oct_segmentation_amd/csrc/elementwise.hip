@@ -270,11 +270,16 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ gradient plumbing
 template <typename T>
-__global__ __launch_bounds__(256) void masked_accum_kernel(void* dst, const void* g, const void* om, size_t nvec) {
+__global__ __launch_bounds__(256) void masked_accum_kernel(void* dst, const void* g, const void* om, size_t nvec, int store) {
   constexpr int VEC = EV<T>::VEC;
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
     float d[VEC], x[VEC];
-    EV<T>::unpack(ldv<T>(dst, v), d);
+    if (store) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+    } else {
+      EV<T>::unpack(ldv<T>(dst, v), d);
+    }
     EV<T>::unpack(ldv<T>(g, v), x);
     if (om) {
       float o[VEC];
@@ -287,16 +292,16 @@ __global__ __launch_bounds__(256) void masked_accum_kernel(void* dst, const void
     stv<T>(dst, v, EV<T>::pack(d));
   }
 }
-hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n, hipStream_t st) {
+hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n, int store, hipStream_t st) {
   const size_t nvec = n / (dtype == DT_F32 ? 4 : 8);
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(masked_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec);
-  else hipLaunchKernelGGL(masked_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec);
+  if (dtype == DT_F32) hipLaunchKernelGGL(masked_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec, store);
+  else hipLaunchKernelGGL(masked_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec, store);
   return hipGetLastError();
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const void* src, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const void* src, int N, int H, int W, int C, int store) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC;
   const size_t nvec = (size_t)N * H * W * vpc;
@@ -307,7 +312,12 @@ __global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const voi
     const int y = (int)(p % H);
     const int n = (int)(p / H);
     float d[VEC];
-    EV<T>::unpack(ldv<T>(dst, v), d);
+    if (store) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+    } else {
+      EV<T>::unpack(ldv<T>(dst, v), d);
+    }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -321,11 +331,11 @@ __global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const voi
     stv<T>(dst, v, EV<T>::pack(d));
   }
 }
-hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C, hipStream_t st) {
+hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C, int store, hipStream_t st) {
   const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(pool2x2_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C);
-  else hipLaunchKernelGGL(pool2x2_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pool2x2_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C, store);
+  else hipLaunchKernelGGL(pool2x2_accum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C, store);
   return hipGetLastError();
 }
 
@@ -398,7 +408,7 @@ hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H
 // gather form: every input pixel re-derives, for each of the <=4 windows that cover it, whether it
 // is that window's first maximum; no atomics, deterministic.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const void* gout, void* gin, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const void* gout, void* gin, int N, int H, int W, int C, int store) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC, OH = H / 2, OW = W / 2;
   const size_t nvec = (size_t)N * H * W * vpc;
@@ -409,7 +419,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const 
     const int iy = (int)(p % H);
     const int n = (int)(p / H);
     float acc[VEC], gi[VEC];
-    EV<T>::unpack(ldv<T>(gin, v), gi);
+    if (store) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gi[i] = 0.f;
+    } else {
+      EV<T>::unpack(ldv<T>(gin, v), gi);
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
@@ -443,11 +458,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const 
     stv<T>(gin, v, EV<T>::pack(gi));
   }
 }
-hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W, int C, hipStream_t st) {
+hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W, int C, int store, hipStream_t st) {
   const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C);
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C, store);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C, store);
   return hipGetLastError();
 }
 

@@ -54,11 +54,11 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
 
-// dst += g * (mask ? out > 0 : 1)   (residual / skip gradient)
-hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n,
+// dst (+)= g * (mask ? out > 0 : 1)   (residual / skip gradient); store = 1: first writer, plain store
+hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n, int store,
                                hipStream_t st);
 // dst[n, y, x, c] += sum_{2x2} src[n, 2y+dy, 2x+dx, c]   (gradient of nearest x2 upsample)
-hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C,
+hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C, int store,
                                 hipStream_t st);
 // per-channel sum over pixels of a NHWC T tensor -> out[c] += sum (bias gradients)
 hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride, int C, float* out,
@@ -68,7 +68,7 @@ hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride
 hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H, int W, int C,
                               hipStream_t st);
 hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W,
-                              int C, hipStream_t st);
+                              int C, int store, hipStream_t st);
 
 // stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the 7x7 s2 p3 conv
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,

@@ -469,6 +469,9 @@ struct Exec {
   char* ws;
   hipStream_t st;
   int train;
+  std::vector<char> ginit;   // backward: has the gradient buffer of tensor t been written yet?
+  // first contribution stores, later ones accumulate
+  int claim(int t) { const int acc = ginit[t] ? 1 : 0; ginit[t] = 1; return acc; }
 
   void* act(int t) const { return ws + P->tensors[t].off; }
   void* grad(int t) const { return ws + P->tensors[t].goff; }
@@ -543,6 +546,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
           a.ndst = 1;
           DstDesc d;
+          d.accum = 0;
           if (L.head) { d.ptr = logits; d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW; }
           else { d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE; }
           a.dst[0] = d;
@@ -613,6 +617,7 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   a.dbeta = E.grads + P->params[b.beta].off;
   a.coef = E.bn_coef(bn);
   a.dy = E.grad(b.y);
+  E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
   HIPCHK(launch_bn_bwd_finalize(a, E.st));
   HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
@@ -644,20 +649,31 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   if (!any) return OCTSEG_OK;
   std::vector<ConvArgs> ld;
   dgrad_launches(g, ld);
-  // destinations: the forward sources' gradient buffers; upsampled sources go through a temp
+  // destinations: the forward sources' gradient buffers; upsampled sources go through a temp.  A destination
+  // that nobody has written yet in this backward is stored to (no memset + read-modify-write), unless this
+  // conv does not cover it completely (1x1 stride 2: only one pixel parity) -- then it is zeroed first.
+  bool full_cover = true;
+  for (auto& a : ld) if (a.ntaps == 0) full_cover = false;
   DstDesc dst[MAX_SRC];
   int nd = 0, c0 = 0;
   int up_src = -1;
   for (size_t i = 0; i < L.srcs.size(); ++i) {
-    const TensorInfo& t = P->tensors[L.srcs[i].v.t];
+    const int ti = L.srcs[i].v.t;
+    const TensorInfo& t = P->tensors[ti];
     DstDesc d;
-    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW;
+    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = 0;
     if (L.srcs[i].up) {
-      d.ptr = E.ws + P->tmp_off;
+      d.ptr = E.ws + P->tmp_off;     // fully covered by this dgrad, pooled into the source afterwards
       up_src = (int)i;
-      HIPCHK(hipMemsetAsync(d.ptr, 0, (size_t)L.N * L.IH * L.IW * t.C * esz, E.st));
+    } else if (!t.need_grad) {
+      d.ptr = E.ws + P->tmp_off; d.accum = 0;   // never happens for multi-source convs; keeps the descriptor valid
     } else {
-      d.ptr = E.grad(L.srcs[i].v.t);
+      d.ptr = E.grad(ti);
+      d.accum = E.claim(ti);
+      if (!d.accum && !full_cover) {
+        HIPCHK(hipMemsetAsync(d.ptr, 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st));
+        d.accum = 1;
+      }
     }
     dst[nd++] = d;
     c0 += t.C;
@@ -666,18 +682,20 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     SrcDesc s;
     s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1;
-    a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of wTt are zero
+    a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero
     a.W = E.ws + L.wimg_dgrad_off;
     for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
     a.ndst = nd;
-    a.out_mode = OUT_ACCUM;
+    a.out_mode = OUT_STORE;   // per-destination accumulate flags decide
     a.bias = nullptr; a.stat_slab = nullptr;
     ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st, L.name);
     HIPCHK(launch_conv(P->dtype, a, E.st));
   }
   if (up_src >= 0) {
     const TensorInfo& t = P->tensors[L.srcs[up_src].v.t];
-    HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(L.srcs[up_src].v.t), E.ws + P->tmp_off, t.N, t.H, t.W, t.C, E.st));
+    const int ti = L.srcs[up_src].v.t;
+    const int acc = E.claim(ti);
+    HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(ti), E.ws + P->tmp_off, t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
   }
   return OCTSEG_OK;
 }
@@ -685,7 +703,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
 static int run_backward(Exec& E, const float* logits, const float* target, float grad_scale) {
   octseg_plan* P = E.P;
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
-  HIPCHK(hipMemsetAsync(E.ws + P->grad_begin, 0, P->grad_end - P->grad_begin, E.st));
+  E.ginit.assign(P->tensors.size(), 0);
   // dL/dlogits (NHWC, padded channels)
   DiceArgs da;
   memset(&da, 0, sizeof(da));
@@ -725,16 +743,20 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
             rc = bn_backward(E, op.res.bn, G, op.relu ? 2 : 0, E.act(op.out));
             if (rc) return rc;
           } else if (P->tensors[op.res.t].need_grad) {
-            HIPCHK(launch_masked_accum(P->dtype, E.grad(op.res.t), G, op.relu ? E.act(op.out) : nullptr, n, E.st));
+            const int acc = E.claim(op.res.t);
+            HIPCHK(launch_masked_accum(P->dtype, E.grad(op.res.t), G, op.relu ? E.act(op.out) : nullptr, n, acc ? 0 : 1, E.st));
           }
         }
-        if (op.post >= 0 && P->tensors[op.post].need_grad)
-          HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, E.st));
+        if (op.post >= 0 && P->tensors[op.post].need_grad) {
+          const int acc = E.claim(op.post);
+          HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, acc ? 0 : 1, E.st));
+        }
         break;
       }
       case OP_MAXPOOL: {
         const TensorInfo& t = P->tensors[op.in];
-        HIPCHK(launch_maxpool_bwd(P->dtype, E.act(op.in), E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, E.st));
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_maxpool_bwd(P->dtype, E.act(op.in), E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
         break;
       }
     }
@@ -918,7 +940,7 @@ int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float*
   for (auto& a : la) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.W = scratch; a.bias = bias;
-    DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW;
+    DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW; d.accum = 0;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr; a.stamp = g_stamp;
     HIPCHK(launch_conv(dtype, a, st));
   }
@@ -943,7 +965,7 @@ int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void*
   for (auto& a : ld) {
     SrcDesc s; s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = Cout; s.c0 = 0; s.H = g.OH; s.W = g.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = scratch; a.bias = nullptr;
-    DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W;
+    DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W; d.accum = 1;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_ACCUM; a.stat_slab = nullptr;
     HIPCHK(launch_conv(dtype, a, st));
   }
