@@ -80,6 +80,7 @@ struct WgradArgs {
   int Cout;         // real number of output channels (rows of dW)
   float* dW;        // [wtaps][Cout][Cin] fp32, accumulated with atomics
   int ksplit;       // number of pixel-tile groups (grid.z)
+  unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only
 };
 
 }  // namespace octseg

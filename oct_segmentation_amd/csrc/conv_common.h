@@ -138,13 +138,13 @@ static __device__ __forceinline__ void stage_window(char* lds, const SrcDesc* sr
 // Pass-wise stager of the input window: pass p covers window pixels [p*PSTEP, (p+1)*PSTEP), one
 // 16-byte channel vector per thread.  load() only issues the global load, write() applies the lazy
 // BN/ReLU and stores to LDS -- the caller puts MFMAs in between so the HBM/L2 latency is hidden.
-template <typename T, int RB, int NT_>
+template <typename T, int RB, int NT_, int PITCH_ = RB + 16>
 struct WindowStager {
   static constexpr int VEC = Tr<T>::VEC;
   static constexpr int KC = RB / (int)sizeof(T);
   static constexpr int VPR = RB / 16;
   static constexpr int PSTEP = NT_ / VPR;
-  static constexpr int PITCH = RB + 16;
+  static constexpr int PITCH = PITCH_;
   SrcSel s;
   float sc[VEC], sh[VEC];
   bool cvalid, has_aff;

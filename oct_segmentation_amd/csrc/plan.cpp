@@ -984,7 +984,7 @@ int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, floa
   wgrad_launches(g, lw);
   for (auto& a : lw) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
-    a.src[0] = s; a.nsrc = 1; a.dy = dy; a.dyC = Cout; a.dW = dw;
+    a.src[0] = s; a.nsrc = 1; a.dy = dy; a.dyC = Cout; a.dW = dw; a.stamp = g_stamp;
     HIPCHK(launch_wgrad(dtype, a, st));
   }
   return OCTSEG_OK;

@@ -18,6 +18,12 @@
 
 namespace octseg {
 
+#ifdef OCTSEG_STAMP
+#define WSTAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WSTAMP(var) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   constexpr int VPR = RB / 16;
   constexpr int PSTEP = NTHR / VPR;
   constexpr int MAXY = 4, MAXW = WgradCfg<NTAPS>::MAXW;
-  typedef WindowStager<T, RB, NTHR> Stager;
+  typedef WindowStager<T, RB, NTHR, PITCH> Stager;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq_m = wave >> 1, wq_n = wave & 1;
@@ -96,18 +102,20 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
     tp.y0 = tyi * th; tp.x0 = (rem - tyi * tiles_x) * TW;
     return tp;
   };
-  // branch-free dy load: clamped address, validity resolved when the vector is written to LDS
-  auto load_y = [&](const TilePos& tp, int pass, bool& ok) {
-    const int p = pass * PSTEP + yp0;
-    const int gy = tp.y0 + (p >> 4), gx = tp.x0 + (p & 15);
-    ok = ycok && p < th * TW && gy < a.OH && gx < a.OW;
+  // branch-free dy load: clamped address, validity resolved when the vector is written to LDS.  All per-pass
+  // coordinates are tile invariant and precomputed; per tile only a 32-bit offset from the image base is formed.
+  const int dy_pix_bytes = a.dyC * (int)sizeof(T), dy_row_bytes = a.DW * dy_pix_bytes;
+  auto load_y = [&](const char* ybase, const TilePos& tp, int ty, int tx, bool in_tile, bool& ok) {
+    const int gy = tp.y0 + ty, gx = tp.x0 + tx;
+    ok = ycok && in_tile && gy < a.OH && gx < a.OW;
     const int gyc = min(gy, a.OH - 1), gxc = min(gx, a.OW - 1);
-    const size_t e = (((size_t)tp.n * a.DH + gyc * a.dstride + a.doy) * a.DW + gxc * a.dstride + a.dox) * a.dyC + (ycok ? yc : 0);
-    return *(const uint4*)((const char*)a.dy + e * sizeof(T));
+    const unsigned off = (unsigned)((gyc * a.dstride + a.doy) * dy_row_bytes + (gxc * a.dstride + a.dox) * dy_pix_bytes);
+    return *(const uint4*)(ybase + off);
   };
   auto write_y = [&](int pass, uint4 v, bool ok) {
     *(uint4*)(ldsY + (pass * PSTEP + yp0) * PITCH + ycv * 16) = ok ? v : make_uint4(0, 0, 0, 0);
   };
+  auto y_base = [&](int n) { return (const char*)a.dy + ((size_t)n * a.DH * a.DW * a.dyC + (ycok ? yc : 0)) * sizeof(T); };
   auto compute = [&]() {
     for (int kk = 0; kk < th; ++kk) {
       const char* yrow = ldsY + kk * TW * PITCH + ya0;
@@ -139,19 +147,39 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
     }
   };
 
+#ifdef OCTSEG_STAMP
+  unsigned long long wts[5] = {0, 0, 0, 0, 0};
+#endif
   if (pipelined) {
     // register-prefetch pipeline: the global loads of tile k+1 fly under the MFMAs of tile k; every
     // load / LDS store is unconditional (clamped indices) so that no wait hides behind a branch.
     uint4 yv[MAXY], xv[MAXW];
     bool yok[MAXY], xok[MAXW];
+    int ypos[MAXY], wpos[MAXW];     // packed (row << 16 | col) of every pass, tile invariant
+    bool yin[MAXY], win[MAXW];
+#pragma unroll
+    for (int u = 0; u < MAXY; ++u) {
+      const int p = min(u, npy - 1) * PSTEP + yp0;
+      ypos[u] = ((p >> 4) << 16) | (p & 15);
+      yin[u] = p < th * TW;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) {
+      const int hp = min(u, npw - 1) * PSTEP + sg.p0;
+      const int hy = (int)(((float)hp + 0.5f) * inv_rw);
+      wpos[u] = (hy << 16) | (hp - hy * RW);
+      win[u] = hp < npix;
+    }
     auto load_tile = [&](int tile) {
       const TilePos tp = tile_pos(tile);
+      const char* yb = y_base(tp.n);
+      sg.bind_image(tp.n);
+      const int gy0 = tp.y0 * a.istride + a.min_dy, gx0 = tp.x0 * a.istride + a.min_dx;
 #pragma unroll
-      for (int u = 0; u < MAXY; ++u) yv[u] = load_y(tp, min(u, npy - 1), yok[u]);
+      for (int u = 0; u < MAXY; ++u) yv[u] = load_y(yb, tp, ypos[u] >> 16, ypos[u] & 0xffff, yin[u], yok[u]);
 #pragma unroll
       for (int u = 0; u < MAXW; ++u)
-        xv[u] = sg.load(min(u, npw - 1), tp.n, tp.y0 * a.istride + a.min_dy, tp.x0 * a.istride + a.min_dx, smul, RW, npix,
-                        inv_rw, a.IH, a.IW, xok[u]);
+        xv[u] = sg.load_at(wpos[u] >> 16, wpos[u] & 0xffff, win[u], gy0, gx0, smul, a.IH, a.IW, xok[u]);
     };
     auto write_tile = [&]() {
 #pragma unroll
@@ -165,13 +193,22 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
       write_tile();
       __syncthreads();
       for (; tile < ntiles; tile += a.ksplit) {
+        unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0; (void)w0; (void)w1; (void)w2; (void)w3; (void)w4;
+        WSTAMP(w0);
         const int nxt = tile + a.ksplit < ntiles ? tile + a.ksplit : tile;  // last round re-fetches (harmless)
         load_tile(nxt);
+        WSTAMP(w1);
         compute();
+        WSTAMP(w2);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // every wave is done reading the tile
+        WSTAMP(w3);
         write_tile();
         __syncthreads();
+        WSTAMP(w4);
+#ifdef OCTSEG_STAMP
+        wts[0] += w1 - w0; wts[1] += w2 - w1; wts[2] += w3 - w2; wts[3] += w4 - w3; wts[4] += 1;
+#endif
       }
     }
   } else {
@@ -181,7 +218,10 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
       for (int p = 0; p < npy; p += MAXY) {
         uint4 v[MAXY]; bool ok[MAXY];
 #pragma unroll
-        for (int u = 0; u < MAXY; ++u) v[u] = load_y(tp, min(p + u, npy - 1), ok[u]);
+        for (int u = 0; u < MAXY; ++u) {
+          const int pp = min(p + u, npy - 1) * PSTEP + yp0;
+          v[u] = load_y(y_base(tp.n), tp, pp >> 4, pp & 15, pp < th * TW, ok[u]);
+        }
 #pragma unroll
         for (int u = 0; u < MAXY; ++u) write_y(min(p + u, npy - 1), v[u], ok[u]);
       }
@@ -199,6 +239,10 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
     }
   }
 
+#ifdef OCTSEG_STAMP
+  if (a.stamp != nullptr && lane == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(a.stamp + i, wts[i]);
+#endif
   // ---- combine: fp32 atomics, lanes 0-31 cover 128 contiguous bytes of one dW row ----
   const int ci = ci0 + wq_n * 32 + (lane & 31);
 #pragma unroll
