@@ -469,6 +469,7 @@ struct Exec {
   char* ws;
   hipStream_t st;
   int train;
+  hipStream_t wst = nullptr;  // stream of the weight-gradient launches (side stream or st)
   std::vector<char> ginit;   // backward: has the gradient buffer of tensor t been written yet?
   // first contribution stores, later ones accumulate
   int claim(int t) { const int acc = ginit[t] ? 1 : 0; ginit[t] = 1; return acc; }
@@ -631,7 +632,12 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   // bias gradient
   if (L.b >= 0)
     HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, E.st));
-  // weight gradient
+  // weight gradient (+ bias gradient) on the side stream: fork after everything that produced dy
+  hipStream_t ws_ = E.wst ? E.wst : E.st;
+  if (ws_ != E.st) {
+    HIPCHK(hipEventRecord(P->ev_fork, E.st));
+    HIPCHK(hipStreamWaitEvent(ws_, P->ev_fork, 0));
+  }
   {
     std::vector<WgradArgs> lw;
     wgrad_launches(g, lw);
@@ -639,8 +645,9 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.nsrc = E.fill_srcs(L, a.src);
       a.dy = dy; a.dyC = dyC;
       a.dW = E.grads + P->params[L.w].off;
-      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), E.st, L.name);
-      HIPCHK(launch_wgrad(P->dtype, a, E.st));
+      a.stamp = nullptr;
+      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), ws_, L.name);
+      HIPCHK(launch_wgrad(P->dtype, a, ws_));
     }
   }
   // data gradient
@@ -704,6 +711,17 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   octseg_plan* P = E.P;
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
   E.ginit.assign(P->tensors.size(), 0);
+  if (!getenv("OCTSEG_NO_SIDE_STREAM")) {
+    if (!P->side) {
+      HIPCHK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
+    }
+    E.wst = P->side;
+    // the side stream must see the zeroed parameter-gradient arena
+    HIPCHK(hipEventRecord(P->ev_fork, E.st));
+    HIPCHK(hipStreamWaitEvent(P->side, P->ev_fork, 0));
+  }
   // dL/dlogits (NHWC, padded channels)
   DiceArgs da;
   memset(&da, 0, sizeof(da));
@@ -761,6 +779,10 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
       }
     }
   }
+  if (E.wst && E.wst != E.st) {   // join: the caller's stream owns the complete gradient arena again
+    HIPCHK(hipEventRecord(P->ev_join, E.wst));
+    HIPCHK(hipStreamWaitEvent(E.st, P->ev_join, 0));
+  }
   return OCTSEG_OK;
 }
 
@@ -792,7 +814,15 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   *out = P;
   return OCTSEG_OK;
 }
-int octseg_plan_destroy(octseg_plan* p) { delete p; return OCTSEG_OK; }
+int octseg_plan_destroy(octseg_plan* p) {
+  if (p) {
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  }
+  delete p;
+  return OCTSEG_OK;
+}
 size_t octseg_plan_workspace_bytes(const octseg_plan* p) { return p ? p->ws_bytes : 0; }
 size_t octseg_plan_param_numel(const octseg_plan* p) { return p ? p->param_numel : 0; }
 size_t octseg_plan_buffer_numel(const octseg_plan* p) { return p ? p->buffer_numel : 0; }

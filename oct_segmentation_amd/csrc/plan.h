@@ -89,4 +89,8 @@ struct octseg_plan {
   int col_tensor = -1;
   int dlogits_C = 16;
   double fwd_macs = 0;
+  // side stream of the backward: weight gradients only depend on dy and on saved activations, so they run
+  // beside the dgrad / BN-backward chain (MFMA-bound next to HBM-bound work)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
