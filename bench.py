@@ -194,8 +194,17 @@ def main():
                 'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
                              for k, m, f in zip(('fwd', 'dgrad', 'wgrad'), ms, fl)},
                 'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
+                'note': 'durations are HIP-event brackets on each launch stream; weight gradients run on a side stream beside the dgrad/BN chain, so the class sums overlap in wall time',
             },
         }
+        # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)
+        tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        if os.path.exists(tpath) and args.workload == 'unetpp_r101_704' and B == 16 and args.dtype == 'bf16':
+            try:
+                out['roofline']['traffic'] = round(json.load(open(tpath))['mfma_family']['hbm_bytes_per_launch'])
+                out['roofline']['traffic_unit'] = 'HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_traffic.json)'
+            except Exception:
+                pass
         note(f'GPU: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; MFMA kernels {ach:.1f} TFLOP/s')
         if not args.no_cpu_baseline and world == 1:
             note('CPU baseline (oracle, 1 frame) ...')
