@@ -285,7 +285,7 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   const size_t lds = wgrad_geom(a, dtype, th).lds;
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
-  int ks = (1024 + gx * gy - 1) / (gx * gy);  // aim at ~1024 workgroups
+  int ks = (512 + gx * gy - 1) / (gx * gy);  // aim at one resident round (2 workgroups per CU): fewer split-K atomics, no tail
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
   a.ksplit = ks;
