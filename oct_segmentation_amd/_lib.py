@@ -84,7 +84,10 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise RuntimeError(f'octseg error {rc}: {lib().octseg_last_error().decode()}')
+        msg = lib().octseg_last_error().decode()
+        if 'Expected more than 1 value per channel' in msg:   # torch raises ValueError for this one
+            raise ValueError(msg)
+        raise RuntimeError(f'octseg error {rc}: {msg}')
 
 
 def ptr(t):

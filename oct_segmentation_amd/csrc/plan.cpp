@@ -527,6 +527,15 @@ static const void* fwd_weight(const Exec& E, const ConvLayer& L) { return E.ws +
 
 static int run_forward(Exec& E, const float* image, float* logits, int normalize, const float* mean, const float* stdv) {
   octseg_plan* P = E.P;
+  if (E.train)
+    for (auto& b : P->bns)
+      if (b.count <= 1.0) {   // torch.nn.functional.batch_norm raises the same way (reference runs it in training)
+        const TensorInfo& t = P->tensors[b.y];
+        char buf[192];
+        snprintf(buf, sizeof buf, "Expected more than 1 value per channel when training, got input size torch.Size([%d, %d, %d, %d])",
+                 t.N, t.C, t.H, t.W);
+        return fail(OCTSEG_BAD_SHAPE, buf);
+      }
   int rc = pack_all_weights(E);
   if (rc) return rc;
   for (auto& op : P->ops) {
