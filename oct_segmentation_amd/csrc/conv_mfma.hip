@@ -39,7 +39,9 @@ namespace octseg {
 template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS = RB / 32, VPR = RB / 16; };
 
 template <typename T, int NT, int WN, int WM, int RB>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a, const int dbuf) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a, const int mode) {
+  const int dbuf = mode & 1;
+  const bool resident = (mode & 2) != 0;   // single K chunk + small slabs: every tap's weights stay in LDS, no per-tap DMA / barrier
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int BN = NT * 32 * WN;
@@ -197,7 +199,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
   {
     Stager cur;
     cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
-    dmaB(a.tap_w[0] * nchunks, 0);
+    if (resident) {
+      for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
+    } else {
+      dmaB(a.tap_w[0] * nchunks, 0);
+    }
     stage_full(cur, ldsA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,7 +292,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       }
     }
   };
-  if (dbuf) {
+  if (resident) {
+    for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
+    __syncthreads();   // the epilogue reuses the LDS
+  } else if (dbuf) {
     if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::true_type{});
   } else {
@@ -441,7 +450,7 @@ hipError_t launch_variant(const ConvArgs& a, int dbuf, size_t lds, hipStream_t s
 
 // Tile choice: N tile from Cout, K chunk from Cin, M tile (16x16 or 8x16 pixels) from tile utilisation
 // and LDS fit (double-buffered window preferred).
-struct Choice { Variant v; int dbuf; size_t lds; };
+struct Choice { Variant v; int dbuf; size_t lds; int resident; };
 
 Choice choose(const ConvArgs& a, int esz) {
   Choice c;
@@ -465,9 +474,18 @@ Choice choose(const ConvArgs& a, int esz) {
       const size_t lds = variant_lds(a, v, esz, pref_dbuf, &npass);
       // the pipeline prefetches 1 pass per tap (4 for 1x1): the next window must fit that budget
       const bool fits_pipe = a.ntaps == 1 ? npass <= 4 : npass <= a.ntaps;
-      if (lds <= cap && (!pref_dbuf || fits_pipe)) { c.v = v; c.dbuf = pref_dbuf; c.lds = lds; return c; }
+      if (lds <= cap && (!pref_dbuf || fits_pipe)) {
+        c.v = v; c.dbuf = pref_dbuf; c.lds = lds; c.resident = 0;
+        // thin layers: one K chunk and slabs small enough to keep all taps in LDS -> no per-tap DMA wait / barrier
+        const size_t slab = (size_t)v.NT * 32 * v.WN * v.RB;
+        if (nchunks_c == 1 && a.ntaps > 1 && a.ntaps * slab <= 40 * 1024) {
+          const size_t extra = (size_t)(a.ntaps - 2) * slab;
+          if (lds + extra <= 64 * 1024) { c.resident = 1; c.lds = lds + extra; }
+        }
+        return c;
+      }
     }
-  c.v = Variant{NT, WN, 2, RB}; c.dbuf = 0; c.lds = variant_lds(a, c.v, esz, 0, nullptr);
+  c.v = Variant{NT, WN, 2, RB}; c.dbuf = 0; c.resident = 0; c.lds = variant_lds(a, c.v, esz, 0, nullptr);
   return c;
 }
 
@@ -478,7 +496,7 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
   const Variant& v = c.v;
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1), c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)
