@@ -100,6 +100,11 @@ int octseg_plan_find_tensor(const octseg_plan* plan, const char* conv_name, size
 int octseg_profile_start(void);
 int octseg_profile_stop(double* out);
 
+/* The forward packs the fp32 parameters into the kernels' weight images (bf16 / f32, LDS-slab order) and
+ * reuses them on later calls with the same (params, workspace) pointers.  Call this after anything that
+ * changes the parameter arena in place: optimizer.step(), load_state_dict(), an all-reduce of parameters. */
+int octseg_plan_params_changed(octseg_plan* plan);
+
 /* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
  * train=1: batch statistics, running buffers updated, activations kept for backward. */
 int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,

@@ -513,6 +513,7 @@ static double layer_macs(const ConvLayer& L) {
 
 static int pack_all_weights(Exec& E) {
   octseg_plan* P = E.P;
+  if (P->packed_valid && P->packed_ws == (const void*)E.ws && P->packed_params == (const void*)E.params) return OCTSEG_OK;
   for (auto& L : P->convs) {
     const ParamInfo& w = P->params[L.w];
     const int taps = L.stem ? 1 : L.R * L.S;
@@ -520,6 +521,7 @@ static int pack_all_weights(Exec& E) {
     if (L.has_dgrad)
       HIPCHK(launch_pack_weight_image(P->dtype, E.params + w.off, E.ws + L.wimg_dgrad_off, taps, L.Cout, L.Cin, 1, L.pk_dgrad, E.st));
   }
+  P->packed_valid = true; P->packed_ws = E.ws; P->packed_params = E.params;
   return OCTSEG_OK;
 }
 
@@ -897,6 +899,14 @@ int octseg_plan_find_tensor(const octseg_plan* p, const char* conv_name, size_t*
       return OCTSEG_OK;
     }
   return fail(OCTSEG_BAD_ARG, std::string("no conv layer named ") + conv_name);
+}
+
+// The packed weight images in the workspace are reused until the caller says the parameters changed
+// (optimizer step, load_state_dict); a fresh plan / another workspace or arena repacks by itself.
+int octseg_plan_params_changed(octseg_plan* p) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  p->packed_valid = false;
+  return OCTSEG_OK;
 }
 
 int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void* workspace, const float* image,

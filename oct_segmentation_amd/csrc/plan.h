@@ -91,6 +91,10 @@ struct octseg_plan {
   double fwd_macs = 0;
   // side stream of the backward: weight gradients only depend on dy and on saved activations, so they run
   // beside the dgrad / BN-backward chain (MFMA-bound next to HBM-bound work)
+  // weight images currently in the workspace correspond to (packed_params, packed_ws) unless invalidated
+  bool packed_valid = false;
+  const void* packed_ws = nullptr;
+  const void* packed_params = nullptr;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

@@ -104,6 +104,7 @@ class SegNet(nn.Module):
         self.dtype_code = _dtype_code(compute_dtype)
         self.device = torch.device(device)
         self._plans = {}
+        self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
         # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
         probe = _Plan(a, encoder_name, self.classes, 1, 32, 32, self.dtype_code)
         lib = L.lib()
@@ -176,6 +177,7 @@ class SegNet(nn.Module):
                 self.bn_buffers[b['mean_offset']:b['mean_offset'] + b['C']] = 0.0
                 self.bn_buffers[b['var_offset']:b['var_offset'] + b['C']] = 1.0
             self.num_batches_tracked.zero_()
+        self.params_changed()
 
     # ------------------------------------------------------------------ state_dict in reference key space
     def state_dict(self, destination=None, prefix='', keep_vars=False):
@@ -214,7 +216,12 @@ class SegNet(nn.Module):
                 k = f"{b['name']}.num_batches_tracked"
                 if k in state_dict:
                     self.num_batches_tracked.copy_(state_dict[k])
+        self.params_changed()   # the views write through arena.data, which torch's version counter does not see
         return nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def params_changed(self):
+        """Tell every plan that the parameter arena was modified outside torch's view (raw pointer writes)."""
+        self._param_epoch += 1
 
     def named_grads(self):
         """Gradients of the last backward, per parameter, in torch layout (for parity tests)."""
@@ -240,6 +247,12 @@ class SegNet(nn.Module):
         x = self._check_input(x)
         B, _, H, W = x.shape
         plan = self._plan(B, H, W)
+        # in-place writes to the arena (torch optimizers, copy_, all-reduce) bump its version counter; the fused
+        # optimizer calls params_changed() itself.  A changed version invalidates every plan's weight images.
+        ver = (self.arena._version, self._param_epoch)
+        if getattr(plan, 'seen_version', None) != ver:
+            L.check(L.lib().octseg_plan_params_changed(plan.handle))
+            plan.seen_version = ver
         logits = torch.empty((B, self.classes, H, W), dtype=torch.float32, device=x.device)
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))

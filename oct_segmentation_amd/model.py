@@ -57,6 +57,7 @@ class FusedOptimizer:
         L.check(L.lib().octseg_optim_step(self.kind, L.ptr(self.net.arena.data), L.ptr(g), L.ptr(self.m), L.ptr(self.v),
                                           self.net.param_numel, self.lr, self.weight_decay, self.step_count,
                                           float(grad_scale), L.stream_ptr()))
+        self.net.params_changed()
 
     def state_dict(self):
         return {'name': self.name, 'step': self.step_count, 'lr': self.lr, 'weight_decay': self.weight_decay,

@@ -23,6 +23,8 @@ def broadcast_parameters(net, src=0):
     """Make every rank start from rank ``src``'s parameters and BN buffers (DDP construction)."""
     dist.broadcast(net.arena.data, src)
     dist.broadcast(net.bn_buffers, src)
+    if hasattr(net, 'params_changed'):
+        net.params_changed()
 
 
 def broadcast_buffers(net, src=0):
