@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -94,12 +95,16 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in the single-GPU gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from oct_segmentation_amd import _lib as L
     from oct_segmentation_amd.model import OCTSegmentationModel

@@ -663,6 +663,49 @@ hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int ta
   return hipGetLastError();
 }
 
+// All weight images of a plan in ONE launch: `tab` lists the jobs, `prefix[j]` = first global vector of job j.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char* ws, const PackJob* tab, const unsigned long long* prefix,
+                                                       int njobs, unsigned long long total) {
+  constexpr int VEC = EV<T>::VEC;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs - 1;   // last job whose prefix <= g
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const PackJob jb = tab[lo];
+    const float* w = params + jb.src_off;
+    const int VPR = jb.RB / 16, KC = jb.RB / (int)sizeof(T), swz_div = 256 / jb.RB;
+    const int rows = jb.transpose ? jb.I : jb.O, K = jb.transpose ? jb.O : jb.I;
+    size_t rem = (size_t)(g - prefix[lo]);
+    const size_t v = rem;
+    const int q = (int)(rem % VPR); rem /= VPR;
+    const int row = (int)(rem % jb.BN); rem /= jb.BN;
+    const int nt = (int)(rem % jb.ntiles); rem /= jb.ntiles;
+    const int chunk = (int)(rem % jb.nchunks);
+    const int tap = (int)(rem / jb.nchunks);
+    const int lq = q ^ ((row / swz_div) & (VPR - 1));
+    const int co = nt * jb.BN + row, c0 = chunk * KC + lq * VEC;
+    float x[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int c = c0 + i;
+      float val = 0.f;
+      if (co < rows && c < K) val = jb.transpose ? w[((size_t)tap * jb.O + c) * jb.I + co] : w[((size_t)tap * jb.O + co) * jb.I + c];
+      x[i] = val;
+    }
+    stv<T>(ws + jb.dst_off, v, EV<T>::pack(x));
+  }
+}
+hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
+                           unsigned long long total, hipStream_t st) {
+  const int gr = grid_for((size_t)total, 256, 8192);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_all_kernel<float>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total);
+  else hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ fused optimizers (torch defaults)
 __global__ __launch_bounds__(256) void optim_kernel(const OptArgs a, float bc1, float bc2, float radam_rect, int radam_use) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {

@@ -92,6 +92,11 @@ hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void*
 hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int taps, int O, int I, int transpose,
                                     const ConvPackInfo& p, hipStream_t st);
 
+// every weight image of a plan in one launch (job table + prefix sums live in the workspace)
+struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, transpose, BN, RB, nchunks, ntiles; };
+hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
+                           unsigned long long total, hipStream_t st);
+
 // fused optimizers over the flat fp32 arenas
 struct OptArgs {
   float* p; const float* g; float* m; float* v; size_t n;

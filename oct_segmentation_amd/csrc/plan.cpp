@@ -448,6 +448,21 @@ static int build_plan(octseg_plan* P) {
     for (auto& s : L.srcs)
       if (s.up) tmp = std::max(tmp, (size_t)L.N * L.IH * L.IW * P->tensors[s.v.t].C * esz);
   }
+  // one-launch weight packing: job table + prefix sums (uploaded into the workspace on first use)
+  P->pack_jobs.clear(); P->pack_prefix.clear(); P->pack_total = 0;
+  for (auto& L : P->convs) {
+    const int taps = L.stem ? 1 : L.R * L.S;
+    for (int tr = 0; tr < 2; ++tr) {
+      if (tr == 1 && !L.has_dgrad) continue;
+      const ConvPackInfo& pk = tr ? L.pk_dgrad : L.pk_fwd;
+      PackJob j{P->params[L.w].off, tr ? L.wimg_dgrad_off : L.wimg_fwd_off, taps, L.Cout, L.Cin, tr, pk.BN, pk.RB, pk.nchunks, pk.ntiles};
+      P->pack_prefix.push_back(P->pack_total);
+      P->pack_jobs.push_back(j);
+      P->pack_total += (unsigned long long)taps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
+    }
+  }
+  P->pack_tab_off = off; off += align_up(P->pack_jobs.size() * sizeof(PackJob));
+  P->pack_prefix_off = off; off += align_up(P->pack_prefix.size() * sizeof(unsigned long long));
   // the BN backward reduce uses up to 1024 slab rows
   for (auto& bn : P->bns) slab = std::max(slab, (size_t)1024 * bn.C * 2 * sizeof(float));
   P->slab_off = off; P->slab_bytes = slab; off += align_up(slab);
@@ -514,13 +529,14 @@ static double layer_macs(const ConvLayer& L) {
 static int pack_all_weights(Exec& E) {
   octseg_plan* P = E.P;
   if (P->packed_valid && P->packed_ws == (const void*)E.ws && P->packed_params == (const void*)E.params) return OCTSEG_OK;
-  for (auto& L : P->convs) {
-    const ParamInfo& w = P->params[L.w];
-    const int taps = L.stem ? 1 : L.R * L.S;
-    HIPCHK(launch_pack_weight_image(P->dtype, E.params + w.off, E.ws + L.wimg_fwd_off, taps, L.Cout, L.Cin, 0, L.pk_fwd, E.st));
-    if (L.has_dgrad)
-      HIPCHK(launch_pack_weight_image(P->dtype, E.params + w.off, E.ws + L.wimg_dgrad_off, taps, L.Cout, L.Cin, 1, L.pk_dgrad, E.st));
+  if (P->pack_tab_ws != (const void*)E.ws) {   // first use of this workspace: upload the job table
+    HIPCHK(hipMemcpyAsync(E.ws + P->pack_tab_off, P->pack_jobs.data(), P->pack_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, E.st));
+    HIPCHK(hipMemcpyAsync(E.ws + P->pack_prefix_off, P->pack_prefix.data(), P->pack_prefix.size() * sizeof(unsigned long long),
+                          hipMemcpyHostToDevice, E.st));
+    P->pack_tab_ws = E.ws;
   }
+  HIPCHK(launch_pack_all(P->dtype, E.params, E.ws, (const PackJob*)(E.ws + P->pack_tab_off),
+                         (const unsigned long long*)(E.ws + P->pack_prefix_off), (int)P->pack_jobs.size(), P->pack_total, E.st));
   P->packed_valid = true; P->packed_ws = E.ws; P->packed_params = E.params;
   return OCTSEG_OK;
 }

@@ -95,6 +95,11 @@ struct octseg_plan {
   bool packed_valid = false;
   const void* packed_ws = nullptr;
   const void* packed_params = nullptr;
+  std::vector<octseg::PackJob> pack_jobs;          // host copy of the pack table
+  std::vector<unsigned long long> pack_prefix;
+  unsigned long long pack_total = 0;
+  size_t pack_tab_off = 0, pack_prefix_off = 0;    // their place in the workspace
+  const void* pack_tab_ws = nullptr;               // workspace the table was last uploaded to
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
