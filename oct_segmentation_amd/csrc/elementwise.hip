@@ -50,43 +50,97 @@ static inline int grid_for(size_t n, int block, int cap = 8192) {
 
 // ------------------------------------------------------------------ BatchNorm finalize
 // one block per 32 channels, 32 row lanes; double accumulation -> deterministic.
-__global__ __launch_bounds__(1024) void bn_finalize_train_kernel(
-    const float* __restrict__ slab, int rows, int C, double count, const float* gamma, const float* beta,
-    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
-    float* mean_out, float* rstd_out) {
+// Deterministic two-level reduction of a [rows][C][2] float slab in double.  Grid (ceil(C/32), G), 1024 threads
+// = 32 channels x 32 row lanes; block (bx, by) sums its slice of rows, and the LAST block of column bx to
+// arrive (ticket counter) adds the G partials in index order.  Returns true on the threads (row lane 0,
+// c < C) of that finishing block, with the totals in s1 / s2.  The counter resets itself.
+__device__ __forceinline__ bool slab_sum(const float* __restrict__ slab, int rows, int C, double* part, unsigned* counters,
+                                         double& s1, double& s2) {
   __shared__ double red[32][33][2];
+  __shared__ unsigned is_last;
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += 32) {
+  const int c = blockIdx.x * 32 + cl, G = gridDim.y;
+  const int per = (rows + G - 1) / G;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  s1 = 0.0; s2 = 0.0;
+  if (c < C) {
+    int r = r0 + rl;
+    for (; r + 96 < r1; r += 128) {   // four independent loads in flight
+      const float2 v0 = *(const float2*)(slab + ((size_t)r * C + c) * 2);
+      const float2 v1 = *(const float2*)(slab + ((size_t)(r + 32) * C + c) * 2);
+      const float2 v2 = *(const float2*)(slab + ((size_t)(r + 64) * C + c) * 2);
+      const float2 v3 = *(const float2*)(slab + ((size_t)(r + 96) * C + c) * 2);
+      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; r < r1; r += 32) {
       const float2 v = *(const float2*)(slab + ((size_t)r * C + c) * 2);
       s1 += (double)v.x; s2 += (double)v.y;
     }
+  }
   red[rl][cl][0] = s1; red[rl][cl][1] = s2;
   __syncthreads();
-  if (rl == 0 && c < C) {
+  const bool owner = rl == 0 && c < C;
+  if (owner)
     for (int r = 1; r < 32; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
-    mean_out[c] = (float)mean;
-    rstd_out[c] = rstd;
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  if (G == 1) return owner;
+  if (owner) {
+    part[((size_t)blockIdx.y * C + c) * 2] = s1;
+    part[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
   }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicAdd(&counters[blockIdx.x], 1u);
+    is_last = old == (unsigned)(G - 1);
+    if (is_last) counters[blockIdx.x] = 0u;
+  }
+  __syncthreads();
+  if (!is_last || !owner) return false;
+  __threadfence();
+  s1 = 0.0; s2 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    s1 += __hip_atomic_load(&part[((size_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s2 += __hip_atomic_load(&part[((size_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
+// row groups of the finalize grid: only a long slab is split (the ticket's fence writes the L2 back, which costs
+// more than it saves below a few thousand rows); G * C <= 4096 partials
+static inline int slab_groups(int rows, int C) {
+  int g = rows / 2048;
+  const int cap = 4096 / (C < 32 ? 32 : C);
+  if (g > cap) g = cap;
+  if (g > 64) g = 64;
+  return g < 1 ? 1 : g;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_train_kernel(
+    const float* __restrict__ slab, int rows, int C, double count, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+    float* mean_out, float* rstd_out, double* part, unsigned* counters) {
+  double s1, s2;
+  if (!slab_sum(slab, rows, C, part, counters, s1, s2)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
 }
 hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double count, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float* scale, float* shift, float* mean,
-                                    float* rstd, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, slab, rows, C, count,
-                     gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+                                    float* rstd, double* part, unsigned* counters, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 31) / 32, slab_groups(rows, C)), dim3(1024), 0, st, slab, rows, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd, part, counters);
   return hipGetLastError();
 }
 
@@ -208,27 +262,16 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
-  __shared__ double red[32][33][2];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < a.C)
-    for (int r = rl; r < a.rows; r += 32) {
-      const float2 v = *(const float2*)(a.slab + ((size_t)r * a.C + c) * 2);
-      s1 += (double)v.x; s2 += (double)v.y;
-    }
-  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
-  __syncthreads();
-  if (rl == 0 && c < a.C) {
-    for (int r = 1; r < 32; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
-    a.dbeta[c] += (float)s1;
-    a.dgamma[c] += (float)s2;
-    a.coef[2 * c] = (float)(s1 / (double)a.npix);
-    a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
-  }
+  double s1, s2;
+  if (!slab_sum(a.slab, a.rows, a.C, a.part, a.counters, s1, s2)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  a.dbeta[c] += (float)s1;
+  a.dgamma[c] += (float)s2;
+  a.coef[2 * c] = (float)(s1 / (double)a.npix);
+  a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
 }
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 31) / 32, slab_groups(a.rows, a.C)), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 

@@ -24,7 +24,8 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double count, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float* scale, float* shift, float* mean,
-                                    float* rstd, hipStream_t st);
+                                    float* rstd, double* part, unsigned* counters, hipStream_t st);
+// `part` (4096 x 2 doubles) and `counters` (64 zeroed uints) are the scratch of the two-level slab reduction.
 // eval: scale/shift from the running statistics.
 hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift,
@@ -49,6 +50,7 @@ struct BnBwdArgs {
   float* dgamma; float* dbeta;           // pass 2 output (fp32 grad arena, accumulated)
   float* coef;                           // [C][2]: (sum dz / M, sum dz*xhat / M)
   void* dy;                              // pass 3 output (may alias g)
+  double* part; unsigned* counters;      // scratch of the two-level slab reduction (pass 2)
 };
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st);

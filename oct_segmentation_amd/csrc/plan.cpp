@@ -466,6 +466,8 @@ static int build_plan(octseg_plan* P) {
   // the BN backward reduce uses up to 1024 slab rows
   for (auto& bn : P->bns) slab = std::max(slab, (size_t)1024 * bn.C * 2 * sizeof(float));
   P->slab_off = off; P->slab_bytes = slab; off += align_up(slab);
+  P->fin_part_off = off; off += align_up(4096 * 2 * sizeof(double));   // two-level slab reduction scratch
+  P->fin_cnt_off = off; off += align_up(64 * sizeof(unsigned));
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)P->classes * 3 * sizeof(double));
@@ -556,6 +558,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       }
   int rc = pack_all_weights(E);
   if (rc) return rc;
+  if (E.train) HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 64 * sizeof(unsigned), E.st));
   for (auto& op : P->ops) {
     switch (op.kind) {
       case OP_STEM_COL: {
@@ -593,7 +596,8 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         if (E.train)
           HIPCHK(launch_bn_finalize_train((const float*)(E.ws + P->slab_off), b.rows, b.C, b.count, gamma, beta,
                                           E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f, 1e-5f, E.bn_scale(op.bn),
-                                          E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), E.st));
+                                          E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), (double*)(E.ws + P->fin_part_off),
+                                          (unsigned*)(E.ws + P->fin_cnt_off), E.st));
         else
           HIPCHK(launch_bn_finalize_eval(b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 1e-5f,
                                          E.bn_scale(op.bn), E.bn_shift(op.bn), E.st));
@@ -635,6 +639,7 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   a.gamma = E.params + P->params[b.gamma].off;
   a.npix = (size_t)t.N * t.H * t.W; a.C = b.C; a.mask = mask;
   a.slab = (float*)(E.ws + P->slab_off);
+  a.part = (double*)(E.ws + P->fin_part_off); a.counters = (unsigned*)(E.ws + P->fin_cnt_off);
   const int VEC = P->dtype == DT_F32 ? 4 : 8;
   const int vpc = b.C / VEC;
   const int tpv = vpc >= 256 ? 1 : 256 / vpc;
@@ -737,6 +742,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
 static int run_backward(Exec& E, const float* logits, const float* target, float grad_scale) {
   octseg_plan* P = E.P;
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
+  HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 64 * sizeof(unsigned), E.st));
   E.ginit.assign(P->tensors.size(), 0);
   if (!getenv("OCTSEG_NO_SIDE_STREAM")) {
     if (!P->side) {

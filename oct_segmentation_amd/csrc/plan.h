@@ -83,6 +83,7 @@ struct octseg_plan {
   size_t ws_bytes = 0;
   size_t act_begin = 0, act_end = 0, grad_begin = 0, grad_end = 0;
   size_t slab_off = 0, slab_bytes = 0;       // BN partial-sum slab (shared, reused per layer)
+  size_t fin_part_off = 0, fin_cnt_off = 0;  // scratch of the two-level slab reduction (BN finalize)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
   size_t dice_off = 0;                       // double sums[C][3]
