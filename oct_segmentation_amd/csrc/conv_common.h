@@ -29,6 +29,13 @@ template <> struct Tr<float> {
     }
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
   }
+  // branch-free form: max(x*scale+shift, lo), lo = 0 (ReLU) or -FLT_MAX (none)
+  static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo) {
+    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = fmaxf(fmaf(x[i], sc[i], sh[i]), lo);
+    return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+  }
   static __device__ __forceinline__ float load(const void* p, size_t i) { return ((const float*)p)[i]; }
   static __device__ __forceinline__ void store(void* p, size_t i, float v) { ((float*)p)[i] = v; }
 };
@@ -50,6 +57,17 @@ template <> struct Tr<bf16_t> {
       hi = fmaf(hi, sc[2 * i + 1], sh[2 * i + 1]);
       if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
       w[i] = pack_bf16(lo, hi);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float l = __uint_as_float(w[i] << 16), h = __uint_as_float(w[i] & 0xffff0000u);
+      l = fmaxf(fmaf(l, sc[2 * i], sh[2 * i]), lo);
+      h = fmaxf(fmaf(h, sc[2 * i + 1], sh[2 * i + 1]), lo);
+      w[i] = pack_bf16(l, h);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   }

@@ -21,8 +21,20 @@ L.check(L.lib().octseg_debug_set_stamp(L.ptr(buf)))
 ops.conv2d_forward(x, w, None, 1, R // 2)
 torch.cuda.synchronize()
 b = buf.cpu().tolist()
+L.check(L.lib().octseg_debug_set_stamp(None))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    ops.conv2d_forward(x, w, None, 1, R // 2)
+e1.record(); torch.cuda.synchronize()
+print(f'stamped build: {e0.elapsed_time(e1) / 5:.3f} ms/iter')
 print(f'{N}x{H}x{W} {Cin}->{Cout} k{R}')
-nc = max(1, b[2]); print(f'consumer wave-iterations {nc}: MFMA block {b[0]/nc:.0f} cyc, barrier wait {b[1]/nc:.0f} cyc')
-na = max(1, b[6]); print(f'producer acting turns {na}: finish(wait+affine+store) {b[3]/na:.0f} cyc, issue {b[4]/na:.0f} cyc, barrier wait {b[5]/na:.0f} cyc')
-print(f'  of which setup() per acting turn: {b[7]/na:.0f} cyc')
+n = max(1, b[5])
+names = ['issue (loads / DMA)', 'MFMA block', 'legacy: LDS write | pipe: vmcnt wait', 'legacy: waits | pipe: transform+lgkm', 'barrier']
+tot = sum(b[:5])
+for i in range(5):
+    print(f'  {names[i]:42s} {b[i] / n:8.1f} ticks/tap  {100.0 * b[i] / tot:5.1f} %')
+print(f'  total {tot / n:.1f} ticks per wave-tap ({n} wave-taps)')
+if b[11]:
+    print(f'  per wave: prologue {b[8] / b[11]:.0f}  main loop {b[9] / b[11]:.0f}  epilogue {b[10] / b[11]:.0f} ticks ({b[11]} waves)')
 shutil.rmtree(tmp, ignore_errors=True)
