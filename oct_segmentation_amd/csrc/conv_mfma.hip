@@ -114,13 +114,15 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     // Fast path (block-uniform): tile fully inside the output, one destination.  Everything below is the same
     // arithmetic in the same order as the general path, minus the per-element bounds checks, the destination
     // search and the per-vector 64-bit address math (the general path is ~4000 instructions per thread).
-    if (!head && a.ndst == 1 && y0 + TH <= a.OH && x0 + TW <= a.OW && co0 + BN <= a.Cout) {
+    if (!head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
       constexpr int ES = (int)sizeof(T);
       const int lbase = (wm * 4 * TW + 4 * h) * OPITCH + (wn * NT * 32 + r) * ES;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         s1[nt] = 0.f; s2[nt] = 0.f;
-        const float bias = a.bias != nullptr ? a.bias[co0 + wn * NT * 32 + nt * 32 + r] : 0.f;
+        const int co = co0 + wn * NT * 32 + nt * 32 + r;
+        const bool cok = co < a.Cout;                       // lanes past Cout: their sums are never stored
+        const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -146,7 +148,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
         }
       }
       __syncthreads();
-      if (a.stat_slab != nullptr && tid < BN) {
+      if (a.stat_slab != nullptr && tid < BN && co0 + tid < a.Cout) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
@@ -156,18 +158,25 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       constexpr int PPI = NTHREADS / OVPR;                  // pixels stored per sweep of the workgroup
       static_assert(BM % PPI == 0 && (PPI % TW == 0 || TW % PPI == 0), "store sweep must tile the block");
       const int p = tid / OVPR, cvv = tid % OVPR;
-      const DstDesc& d = a.dst[0];
-      const size_t pixb = (size_t)d.C * ES * a.ostride;     // bytes between horizontally adjacent outputs
-      const size_t rowb = (size_t)d.W * d.C * ES * a.ostride;
+      const int cov = co0 + cvv * VEC;                      // this thread's channel vector: the same in every sweep
+      if (cov >= a.Cout) return;
+      char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W, dacc = a.dst[0].accum;
+#pragma unroll
+      for (int i = 1; i < MAX_SRC; ++i)
+        if (i < a.ndst && cov >= a.dst[i].c0) {
+          dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W; dacc = a.dst[i].accum;
+        }
+      const size_t pixb = (size_t)dC * ES * a.ostride;      // bytes between horizontally adjacent outputs
+      const size_t rowb = (size_t)dW * dC * ES * a.ostride;
       const int oy = (y0 + (p >> 4)) * a.ostride + a.ooy, ox = (x0 + (p & 15)) * a.ostride + a.oox;
-      char* gp = (char*)d.ptr + ((((size_t)n * d.H + oy) * d.W + ox) * d.C + (co0 + cvv * VEC - d.c0)) * ES;
+      char* gp = dptr + ((((size_t)n * dH + oy) * dW + ox) * dC + (cov - dc0)) * ES;
       // sweep k covers pixels p + k*PPI: whole rows further down, or (PPI < 16) the next piece of the same row
       auto gstep_of = [&](int k) -> size_t {
         if constexpr (PPI % TW == 0) return (size_t)(PPI / TW) * rowb;
         else return ((k + 1) % (TW / PPI) == 0) ? rowb - (size_t)(TW - PPI) * pixb : (size_t)PPI * pixb;
       };
       const char* lp = otile + p * OPITCH + cvv * 16;
-      if (a.out_mode == OUT_ACCUM || d.accum) {
+      if (a.out_mode == OUT_ACCUM || dacc) {
 #pragma unroll 4
         for (int k = 0; k < BM / PPI; ++k) {
           uint4 val = *(const uint4*)(lp + k * PPI * OPITCH);
