@@ -1057,7 +1057,15 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
     return (double)a.OH * a.OW / (ty * TH * tx * TW);
   };
   const size_t cap = 160 * 1024;
-  const int wm_first = util(8) > 1.15 * util(16) ? 2 : 4;
+  int wm_first = util(8) > 1.15 * util(16) ? 2 : 4;
+  // 1x1 convs and single-chunk (resident-tap) layers run a handful of iterations per tile: what they need is
+  // several small workgroups per CU, so that one's prologue / epilogue hides under another's MFMAs
+  // (measured +6..23 % on the ResNet bottleneck shapes); the 8x16 tile costs them no halo worth mentioning
+  {
+    const int kc = (a.Cin <= (128 / esz) / 2 ? 64 : 128) / esz;
+    if (a.ntaps == 1 || a.Cin <= kc) wm_first = 2;
+  }
+  if (getenv("OCTSEG_FORCE_WM")) wm_first = atoi(getenv("OCTSEG_FORCE_WM"));   // experiments only
   const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};
   const int nchunks_c = (a.Cin + RB / esz - 1) / (RB / esz);
   // a single K chunk never restages its window: a second buffer would only cost occupancy
