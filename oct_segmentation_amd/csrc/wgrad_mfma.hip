@@ -35,7 +35,9 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VEC = Tr<T>::VEC;
   constexpr int RB = 64 * (int)sizeof(T);  // 64 channels per LDS row
-  constexpr int PITCH = RB + 16;
+  // bf16: the transposed reads of a 32-lane group touch 4 pixel rows x 16 banks each: the row pitch must move the
+  // bank by 16 (mod 64) per row -> 192 bytes (144 makes rows 0/2 and 1/3 collide: every read 2-way conflicted)
+  constexpr int PITCH = sizeof(T) == 2 ? 192 : RB + 16;
   constexpr int VPR = RB / 16;
   constexpr int PSTEP = NTHR / VPR;
   constexpr int MAXY = 4, MAXW = WgradCfg<NTAPS>::MAXW;
@@ -117,23 +119,64 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   };
   auto y_base = [&](int n) { return (const char*)a.dy + ((size_t)n * a.DH * a.DW * a.dyC + (ycok ? yc : 0)) * sizeof(T); };
   auto compute = [&]() {
-    for (int kk = 0; kk < th; ++kk) {
-      const char* yrow = ldsY + kk * TW * PITCH + ya0;
-      const char* xrow = ldsX + (kk * lstride) * RW * PITCH + xa0;
-      if constexpr (sizeof(T) == 2) {
-        struct Pair { s16x4_t lo, hi; };  // two transposed 4-element reads = one 8-element MFMA fragment
+    if constexpr (sizeof(T) == 2) {
+      // One wave per SIMD (the NTAPS accumulators leave no room for a second): nobody else hides this wave's LDS
+      // latency, so the transposed fragment reads of pixel row kk+1 are issued before the MFMAs of row kk
+      // (two register sets; the spare half of the 512-register file pays for them).
+      struct Pair { s16x4_t lo, hi; };  // two transposed 4-element reads = one 8-element MFMA fragment
+      struct Frags { uint4 y; uint4 x[NTAPS]; };
+      auto load_frags = [&](int kk, Frags& f) {
+        const char* yrow = ldsY + kk * TW * PITCH + ya0;
+        const char* xrow = ldsX + (kk * lstride) * RW * PITCH + xa0;
         Pair ya;
         ya.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
         ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
-        const uint4 af = __builtin_bit_cast(uint4, ya);
+        f.y = __builtin_bit_cast(uint4, ya);
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
           Pair xb;
           xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
           xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
-          Tr<T>::mma(af, __builtin_bit_cast(uint4, xb), acc[t]);
+          f.x[t] = __builtin_bit_cast(uint4, xb);
         }
-      } else {
+      };
+      auto load_y1 = [&](int kk, Frags& f) {
+        const char* yrow = ldsY + kk * TW * PITCH + ya0;
+        Pair ya;
+        ya.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
+        ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
+        f.y = __builtin_bit_cast(uint4, ya);
+      };
+      auto load_x1 = [&](const char* xrow, int t, Frags& f) {
+        Pair xb;
+        xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
+        xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
+        f.x[t] = __builtin_bit_cast(uint4, xb);
+      };
+      // MFMAs of row `cur`, the fragment reads of row kn spread between them (two reads per MFMA gap)
+      auto row_step = [&](const Frags& cur, int kn, Frags& nxt) {
+        const char* xrow = ldsX + (kn * lstride) * RW * PITCH + xa0;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+          Tr<T>::mma(cur.y, cur.x[t], acc[t]);
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef OCTSEG_EXP_NOFRAG   // timing experiment: MFMAs on stale fragments
+          if (t == 0) load_y1(kn, nxt);
+          load_x1(xrow, t, nxt);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      Frags fa, fb;
+      load_frags(0, fa);
+      for (int kk = 0; kk < th; kk += 2) {       // th is even on this path (2, 4 or 8); rows past th - 1 are re-reads
+        row_step(fa, min(kk + 1, th - 1), fb);
+        if (kk + 1 < th) row_step(fb, min(kk + 2, th - 1), fa);
+      }
+    } else {
+      for (int kk = 0; kk < th; ++kk) {
+        const char* yrow = ldsY + kk * TW * PITCH + ya0;
+        const char* xrow = ldsX + (kk * lstride) * RW * PITCH + xa0;
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp) {
           const float yv = *(const float*)(yrow + kp * 2 * PITCH);
@@ -258,7 +301,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
 
 struct WgradGeom { int npy, npw; size_t lds; };
 static WgradGeom wgrad_geom(const WgradArgs& a, int dtype, int th) {
-  const int RB = 64 * (int)dtype_size(dtype), PITCH = RB + 16, PSTEP = NTHR / (RB / 16);
+  const int RB = 64 * (int)dtype_size(dtype), PITCH = dtype_size(dtype) == 2 ? 192 : RB + 16, PSTEP = NTHR / (RB / 16);
   const bool single = a.ntaps == 1;
   const int RH = single ? th : (th - 1) * a.istride + a.span_y;
   const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
@@ -285,7 +328,7 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   const size_t lds = wgrad_geom(a, dtype, th).lds;
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
-  int ks = (512 + gx * gy - 1) / (gx * gy);  // aim at one resident round (2 workgroups per CU): fewer split-K atomics, no tail
+  int ks = 512 / (gx * gy);  // one resident round at most (two workgroup slots per CU): 516 workgroups take twice as long as 504
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
   a.ksplit = ks;
