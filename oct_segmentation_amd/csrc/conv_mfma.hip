@@ -306,8 +306,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
 
 template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS = RB / 32, VPR = RB / 16; };
 
+// 4-wave variants must leave room for a second workgroup per CU (<= 256 registers): they serve the short layers
+// whose prologue / epilogue only hides under another workgroup's MFMAs
 template <typename T, int NT, int WN, int WM, int RB>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a, const int mode) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
   const int dbuf = mode & 1;
   const bool resident = (mode & 2) != 0;   // single K chunk + small slabs: every tap's weights stay in LDS, no per-tap DMA / barrier
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -534,9 +536,68 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
       }
     }
   };
+  // 3x3 taps, double-buffered window: the chunk body is written out tap by tap so that the window slice loaded
+  // in tap t is stored to LDS at the end of tap t + 1 -- a whole tap of MFMAs later instead of the same tap
+  // (stamps: that same-tap wait cost ~800 of a tap's ~2900 cycles).  Two named register sets alternate, so no
+  // register copy ever touches a load in flight; hipcc counts its own loads (vmcnt(1) in front of the store:
+  // only the newest window load may be outstanding, which also retires the slab DMA issued before it), and the
+  // explicit wait in front of the barrier leaves exactly that newest load in flight.
+  auto run9 = [&]() {
+    int it = 0;
+    int tap2 = 1, chunk2 = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool has_next = chunk + 1 < nchunks;
+      Stager nxt;
+      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid);
+      nxt.bind_image(n);
+      const char* awin = ldsA + ((chunk & 1) ? abytes : 0);
+      char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
+      int hy = hy_first, hx = hx_first, hp = p0w;
+      char* wrow = anext + p0w * PITCH;
+      uint4 avA = make_uint4(0, 0, 0, 0), avB = make_uint4(0, 0, 0, 0);
+      bool okA = false, okB = false;
+      char* wrA = wrow; char* wrB = wrow;
+      auto tap = [&](auto tc) {
+        constexpr int TT = decltype(tc)::value;
+        // slab of the next iteration first, then the window slice: the slice is the NEWEST operation in flight
+        dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, (it + 1) & 1);
+        if constexpr (TT < 8) {
+          uint4& av = (TT & 1) ? avB : avA;
+          bool& ok = (TT & 1) ? okB : okA;
+          char*& wr = (TT & 1) ? wrB : wrA;
+          av = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok);
+          wr = wrow;
+          const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+          if (adv) {
+            hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
+            hy += dq; hx += dr;
+            if (hx >= RW) { hx -= RW; hy += 1; }
+          }
+        }
+        const int toff = __builtin_amdgcn_readlane(v_toff, TT);
+        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TT >= 1) {   // store the slice loaded one tap ago
+          if ((TT - 1) & 1) nxt.write_at(wrB, avB, okB); else nxt.write_at(wrA, avA, okA);
+        }
+        if constexpr (TT < 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (++tap2 == 9) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
+        ++it;
+      };
+      tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+      tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+      tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    }
+  };
   if (resident) {
     for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
     __syncthreads();   // the epilogue reuses the LDS
+  } else if (dbuf && ntaps == 9 && npass <= 8 && !(mode & 8)) {
+    run9();
   } else if (dbuf) {
     if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::true_type{});
@@ -1110,7 +1171,7 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
   }
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0), c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0) | (getenv("OCTSEG_NO_RUN9") ? 8 : 0), c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)
