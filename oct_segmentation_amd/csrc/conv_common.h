@@ -184,6 +184,21 @@ struct WindowStager {
     const unsigned off = (unsigned)((iyc >> s.up) * row_bytes + (ixc >> s.up) * pix_bytes);
     return *(const uint4*)(img_base + off);
   }
+  // address half of load_at (for callers that issue the load themselves)
+  __device__ __forceinline__ const char* addr_at(int hy, int hx, bool in_window, int gy0, int gx0, int smul, int IH, int IW,
+                                                 bool& ok) const {
+    const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
+    ok = cvalid && in_window && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+    const int iyc = min(max(iy, 0), IH - 1), ixc = min(max(ix, 0), IW - 1);
+    const unsigned off = (unsigned)((iyc >> s.up) * row_bytes + (ixc >> s.up) * pix_bytes);
+    return img_base + off;
+  }
+  // value half of write_at: lazy BN / ReLU, zero outside the image
+  __device__ __forceinline__ uint4 prep(uint4 v, bool ok) const {
+    if (has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return v;
+  }
   __device__ __forceinline__ void write_at(char* lds_row, uint4 v, bool ok) const {
     if (has_aff) v = Tr<T>::affine(v, sc, sh, s.relu);
     if (!ok) v = make_uint4(0, 0, 0, 0);

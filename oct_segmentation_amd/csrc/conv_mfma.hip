@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
 
   const int abytes = npass * Stager::PSTEP * PITCH;   // rows padded to whole passes (unconditional stores)
   char* ldsA = smem;                                  // [1 or 2] windows
-  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slab ring
+  char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slab ring ([3] in the run9 ring mode)
 
   f32x16_t acc[2][NT];
 #pragma unroll
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
 #pragma unroll
       for (int j = 0; j < DPW; ++j) {
         const char* gsrc = gsrc0 + j * 1024;
-        const unsigned dst = ldsB_addr + slot * BBYTES + (wave_u * DPW + j) * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ldsB_addr + slot * BBYTES + (wave_u * DPW + j) * 1024);
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -439,6 +439,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     }
   };
 
+  // the same with filler work behind the MFMAs of k-steps 0, 1 and 2 (RB = 128: four k-steps): the MFMAs just
+  // issued execute while the wave runs the filler, instead of every wave leaving the pipe idle in a common
+  // issue / store phase at the end of the tap
+  auto mma_tap_f = [&](const char* awin, const char* bsl, int toff, auto&& f0, auto&& f1, auto&& f2) __attribute__((always_inline)) {
+    uint4 af[3][2], bf[3][NT];
+    auto frag_load = [&](int buf, int ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
+    };
+    frag_load(0, 0);
+    if (KSTEPS > 1) frag_load(1, 1);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) f0();
+      if (ks == 1) f1();
+      if (ks == 2) f2();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   // ---------------- prologue: window of chunk 0 + first weight slab ----------------
   {
     Stager cur;
@@ -447,6 +476,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
     } else {
       dmaB(a.tap_w[0] * nchunks, 0);
+      if (mode & 16) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring (run9r): two slabs ahead
     }
     stage_full(cur, ldsA);
   }
@@ -536,15 +566,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       }
     }
   };
-  // 3x3 taps, double-buffered window: the chunk body is written out tap by tap so that the window slice loaded
-  // in tap t is stored to LDS at the end of tap t + 1 -- a whole tap of MFMAs later instead of the same tap
-  // (stamps: that same-tap wait cost ~800 of a tap's ~2900 cycles).  Two named register sets alternate, so no
-  // register copy ever touches a load in flight; hipcc counts its own loads (vmcnt(1) in front of the store:
-  // only the newest window load may be outstanding, which also retires the slab DMA issued before it), and the
-  // explicit wait in front of the barrier leaves exactly that newest load in flight.
-  auto run9 = [&]() {
+  // 3x3 taps, double-buffered window, THREE-slot slab ring (host: only when LDS allows): the chunk body is written
+  // out tap by tap.  The window slice loaded in tap t is stored to LDS at the end of tap t + 1 -- a whole tap of
+  // MFMAs later (stamps: waiting for it in the same tap cost ~800 of a tap's ~2900 cycles) -- and the slabs are
+  // fetched two taps ahead.  Every prefetch is outside hipcc's waitcnt bookkeeping: per tap the slab DMA is issued
+  // first, then the slice, and the only wait of a tap is `vmcnt(what this tap issued)`: everything the previous tap
+  // issued has landed -- the next tap's slab and the slice stored now.  The slice load is an asm global_load
+  // (hipcc does not know the DMAs and would wait for the younger ones too); its destination is named "+v" in the
+  // wait statement, so no consumer can be scheduled in front of the wait, and the two register sets are separate
+  // variables of fully unrolled code.  tools/audit_asm_loads.py checks in the ISA that no instruction touches a
+  // destination between its load and its wait ('asm load' rule of cdna_hip_programming.md); run it after any edit.
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  auto run9r = [&]() __attribute__((always_inline)) {
+    constexpr int D = 3;
     int it = 0;
-    int tap2 = 1, chunk2 = 0;
+    int tap2 = D - 1, chunk2 = 0;                   // slab cursor: iteration it + D - 1
+    int slotC = 0, slotS = D - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool has_next = chunk + 1 < nchunks;
       Stager nxt;
@@ -554,37 +591,72 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
       int hy = hy_first, hx = hx_first, hp = p0w;
       char* wrow = anext + p0w * PITCH;
-      uint4 avA = make_uint4(0, 0, 0, 0), avB = make_uint4(0, 0, 0, 0);
+      u32x4_t avA = {0, 0, 0, 0}, avB = {0, 0, 0, 0};
       bool okA = false, okB = false;
       char* wrA = wrow; char* wrB = wrow;
-      auto tap = [&](auto tc) {
+      auto tap = [&](auto tc) __attribute__((always_inline)) {
         constexpr int TT = decltype(tc)::value;
-        // slab of the next iteration first, then the window slice: the slice is the NEWEST operation in flight
-        dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, (it + 1) & 1);
-        if constexpr (TT < 8) {
-          uint4& av = (TT & 1) ? avB : avA;
-          bool& ok = (TT & 1) ? okB : okA;
-          char*& wr = (TT & 1) ? wrB : wrA;
-          av = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok);
-          wr = wrow;
-          const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
-          if (adv) {
-            hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
-            hy += dq; hx += dr;
-            if (hx >= RW) { hx -= RW; hy += 1; }
-          }
-        }
+        constexpr int W = TT < 8 ? 1 : 0;            // a slice is issued in this tap
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+        (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5;
+        STAMP(s0);
         const int toff = __builtin_amdgcn_readlane(v_toff, TT);
-        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
+        const char* bsl = ldsB + slotC * BBYTES;
+        if (++slotC == D) slotC = 0;
+        uint4 wv = make_uint4(0, 0, 0, 0);
+        STAMP(s1);
+        mma_tap_f(awin, bsl, toff,
+          [&]() {   // behind k-step 0: this tap's prefetches (slab of iteration it + 2 first, then the slice)
+#ifndef OCTSEG_EXP_NOSLAB   // timing experiments only
+            dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, slotS);
+#endif
+            if (++slotS == D) slotS = 0;
+            if constexpr (TT < 8) {
+              bool& ok = (TT & 1) ? okB : okA;
+              char*& wr = (TT & 1) ? wrB : wrA;
+              const char* g = nxt.addr_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok);
+#ifndef OCTSEG_EXP_NOSLICE
+              if constexpr (TT & 1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(avB) : "v"(g));
+              else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(avA) : "v"(g));
+#else
+              (void)g;
+#endif
+              wr = wrow;
+              const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+              if (adv) {
+                hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
+                hy += dq; hx += dr;
+                if (hx >= RW) { hx -= RW; hy += 1; }
+              }
+            }
+          },
+          [&]() {   // behind k-step 1: everything the previous tap issued has landed (this tap's DPW + W operations
+                    // may fly): the slab of the next tap, and the slice loaded one tap ago -> lazy BN / ReLU on it
+            if constexpr (TT >= 1) {
+              if constexpr ((TT - 1) & 1) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(avB) : "n"(DPW + W) : "memory");
+                wv = nxt.prep(__builtin_bit_cast(uint4, avB), okB);
+              } else {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(avA) : "n"(DPW + W) : "memory");
+                wv = nxt.prep(__builtin_bit_cast(uint4, avA), okA);
+              }
+            } else {
+              asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + W) : "memory");
+            }
+          },
+          [&]() {   // behind k-step 2: its LDS store
+            if constexpr (TT >= 1) *(uint4*)((((TT - 1) & 1) ? wrB : wrA) + nxt.cv * 16) = wv;
+          });
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TT >= 1) {   // store the slice loaded one tap ago
-          if ((TT - 1) & 1) nxt.write_at(wrB, avB, okB); else nxt.write_at(wrA, avA, okA);
-        }
-        if constexpr (TT < 8) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(s2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(s4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(s5);
+#ifdef OCTSEG_STAMP
+        tsum[0] += s1 - s0; tsum[1] += s2 - s1; tsum[3] += s4 - s2; tsum[4] += s5 - s4; tsum[5] += 1;
+#endif
         if (++tap2 == 9) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
         ++it;
       };
@@ -592,12 +664,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
       tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail slabs
+    __syncthreads();
   };
   if (resident) {
     for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
     __syncthreads();   // the epilogue reuses the LDS
-  } else if (dbuf && ntaps == 9 && npass <= 8 && !(mode & 8)) {
-    run9();
+  } else if (dbuf && ntaps == 9 && npass <= 8 && (mode & 16) && !(mode & 8) && NDMA % NWAVES == 0) {
+    run9r();
   } else if (dbuf) {
     if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::true_type{});
@@ -1061,7 +1135,7 @@ hipError_t launch_pipe(const ConvArgs& a, int D, size_t lds, hipStream_t st) {
 
 // Tile choice: N tile from Cout, K chunk from Cin, M tile (16x16 or 8x16 pixels) from tile utilisation
 // and LDS fit (double-buffered window preferred).
-struct Choice { Variant v; int dbuf; size_t lds; int resident; int pipe; };   // pipe = ring depth D of conv_pipe_kernel (0: conv_mfma_kernel)
+struct Choice { Variant v; int dbuf; size_t lds; int resident; int pipe; int ring3; };   // pipe = ring depth D of conv_pipe_kernel (0: conv_mfma_kernel)
 
 // LDS of conv_pipe_kernel at ring depth D (0 if the pipeline does not fit this geometry)
 size_t pipe_lds(const ConvArgs& a, const Variant& v, int esz, int D) {
@@ -1108,7 +1182,7 @@ Choice choose(const ConvArgs& a, int esz) {
 
 static Choice choose_legacy(const ConvArgs& a, int esz) {
   Choice c;
-  c.pipe = 0;
+  c.pipe = 0; c.ring3 = 0;
   int NT, WN;
   if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
   const int kc128 = 128 / esz;
@@ -1139,6 +1213,13 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
       const bool fits_pipe = a.ntaps == 1 ? npass <= 4 : npass <= a.ntaps;
       if (lds <= cap && (!pref_dbuf || fits_pipe)) {
         c.v = v; c.dbuf = pref_dbuf; c.lds = lds; c.resident = 0;
+        // 3x3 double-buffered: a third slab slot if LDS allows (slabs are then fetched two taps ahead)
+        {
+          const size_t slab = (size_t)v.NT * 32 * v.WN * v.RB;
+          const int nd = (int)(slab / 1024), nw = v.WM * v.WN;
+          static const bool no_ring3 = getenv("OCTSEG_NO_RING3") != nullptr;
+          if (!no_ring3 && pref_dbuf && a.ntaps == 9 && npass <= 8 && nd % nw == 0 && lds + slab <= cap) { c.ring3 = 1; c.lds = lds + slab; }
+        }
         // thin layers: one K chunk and slabs small enough to keep all taps in LDS -> no per-tap DMA wait / barrier
         const size_t slab = (size_t)v.NT * 32 * v.WN * v.RB;
         if (nchunks_c == 1 && a.ntaps > 1 && a.ntaps * slab <= 40 * 1024) {
@@ -1171,7 +1252,7 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
   }
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0) | (getenv("OCTSEG_NO_RUN9") ? 8 : 0), c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0) | (getenv("OCTSEG_NO_RUN9") ? 8 : 0) | (c.ring3 ? 16 : 0), c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)

@@ -6,7 +6,7 @@ csrc = os.path.join(root, 'oct_segmentation_amd', 'csrc')
 tmp = tempfile.mkdtemp()
 so = os.path.join(tmp, 'liboctseg_stamp.so')
 srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'plan.cpp')]
-subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-DOCTSEG_STAMP', '-o', so] + srcs, check=True)
+subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-DOCTSEG_STAMP'] + os.environ.get('OCTSEG_EXTRA_DEFS', '').split() + ['-o', so] + srcs, check=True)
 sys.path.insert(0, root)
 import torch
 from oct_segmentation_amd import _lib as L
@@ -30,7 +30,7 @@ e1.record(); torch.cuda.synchronize()
 print(f'stamped build: {e0.elapsed_time(e1) / 5:.3f} ms/iter')
 print(f'{N}x{H}x{W} {Cin}->{Cout} k{R}')
 n = max(1, b[5])
-names = ['issue (loads / DMA)', 'MFMA block', 'legacy: LDS write | pipe: vmcnt wait', 'legacy: waits | pipe: transform+lgkm', 'barrier']
+names = ['issue (slab DMA, slice load)', 'MFMA block', 'vmcnt wait', 'affine + LDS store + lgkm', 'barrier']
 tot = sum(b[:5])
 for i in range(5):
     print(f'  {names[i]:42s} {b[i] / n:8.1f} ticks/tap  {100.0 * b[i] / tot:5.1f} %')
