@@ -679,6 +679,8 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.dW = E.grads + P->params[L.w].off;
       a.stamp = nullptr;
       ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), ws_, L.name);
+      static const bool skip_wgrad = getenv("OCTSEG_EXP_SKIP_WGRAD") != nullptr;   // timing experiment only
+      if (skip_wgrad) continue;
       HIPCHK(launch_wgrad(P->dtype, a, ws_));
     }
   }
