@@ -105,6 +105,12 @@ int octseg_profile_stop(double* out);
  * changes the parameter arena in place: optimizer.step(), load_state_dict(), an all-reduce of parameters. */
 int octseg_plan_params_changed(octseg_plan* plan);
 
+/* Serving path (reference: src/models/smp/predict.py segment(), model.py:183-200 predict()): enable = 1 makes every
+ * eval-mode octseg_net_forward of this plan run as a hipGraph -- the first call with a given argument set runs
+ * eagerly, the second is captured, later ones replay it (one launch instead of ~400) for as long as the pointers,
+ * the stream and the normalisation constants stay the same.  Keep the image / logits in persistent buffers. */
+int octseg_plan_set_graph(octseg_plan* plan, int enable);
+
 /* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
  * train=1: batch statistics, running buffers updated, activations kept for backward. */
 int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,

@@ -153,6 +153,29 @@ __global__ void bn_finalize_eval_kernel(int C, const float* gamma, const float* 
     shift[c] = beta[c] - rm[c] * sc;
   }
 }
+// every BatchNorm of a plan in one launch (eval): job j covers channels [prefix[j], prefix[j+1])
+__global__ __launch_bounds__(256) void bn_finalize_eval_all_kernel(const float* params, const float* buffers, char* ws, const BnEvalJob* tab,
+                                                                   const unsigned* prefix, int njobs, unsigned total, float eps) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  const BnEvalJob jb = tab[lo];
+  const int c = (int)(g - prefix[lo]);
+  const float sc = params[jb.gamma_off + c] / sqrtf(buffers[jb.rv_off + c] + eps);
+  float* ss = (float*)(ws + jb.ss_off);
+  ss[c] = sc;
+  ss[jb.C + c] = params[jb.beta_off + c] - buffers[jb.rm_off + c] * sc;
+}
+hipError_t launch_bn_finalize_eval_all(const float* params, const float* buffers, void* ws, const BnEvalJob* tab, const unsigned* prefix,
+                                       int njobs, unsigned total, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_eval_all_kernel, dim3((total + 255) / 256), dim3(256), 0, st, params, buffers, (char*)ws, tab, prefix,
+                     njobs, total, eps);
+  return hipGetLastError();
+}
 hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift,
                                    hipStream_t st) {

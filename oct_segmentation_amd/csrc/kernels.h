@@ -31,6 +31,11 @@ hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta,
                                    const float* running_var, float eps, float* scale, float* shift,
                                    hipStream_t st);
 
+// eval: scale/shift of every BatchNorm of a plan in one launch (job table + channel prefix sums in the workspace)
+struct BnEvalJob { size_t gamma_off, beta_off, rm_off, rv_off /*floats*/, ss_off /*bytes*/; int C; };
+hipError_t launch_bn_finalize_eval_all(const float* params, const float* buffers, void* ws, const BnEvalJob* tab, const unsigned* prefix,
+                                       int njobs, unsigned total, float eps, hipStream_t st);
+
 // out = relu?( y*scale+shift [+ res*rscale+rshift | + res] ) [+ post]   (NHWC, T)
 struct BnActArgs {
   const void* y; const float* scale; const float* shift;

@@ -461,6 +461,14 @@ static int build_plan(octseg_plan* P) {
       P->pack_total += (unsigned long long)taps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
     }
   }
+  P->bn_jobs.clear(); P->bn_prefix.clear(); P->bn_total = 0;
+  for (auto& b : P->bns) {
+    P->bn_prefix.push_back(P->bn_total);
+    P->bn_jobs.push_back(BnEvalJob{P->params[b.gamma].off, P->params[b.beta].off, b.rm_off, b.rv_off, b.ss_off, b.C});
+    P->bn_total += (unsigned)b.C;
+  }
+  P->bn_tab_off = off; off += align_up(P->bn_jobs.size() * sizeof(BnEvalJob));
+  P->bn_prefix_off = off; off += align_up(P->bn_prefix.size() * sizeof(unsigned));
   P->pack_tab_off = off; off += align_up(P->pack_jobs.size() * sizeof(PackJob));
   P->pack_prefix_off = off; off += align_up(P->pack_prefix.size() * sizeof(unsigned long long));
   // the BN backward reduce uses up to 1024 slab rows
@@ -535,6 +543,10 @@ static int pack_all_weights(Exec& E) {
     HIPCHK(hipMemcpyAsync(E.ws + P->pack_tab_off, P->pack_jobs.data(), P->pack_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, E.st));
     HIPCHK(hipMemcpyAsync(E.ws + P->pack_prefix_off, P->pack_prefix.data(), P->pack_prefix.size() * sizeof(unsigned long long),
                           hipMemcpyHostToDevice, E.st));
+    if (!P->bn_jobs.empty()) {
+      HIPCHK(hipMemcpyAsync(E.ws + P->bn_tab_off, P->bn_jobs.data(), P->bn_jobs.size() * sizeof(BnEvalJob), hipMemcpyHostToDevice, E.st));
+      HIPCHK(hipMemcpyAsync(E.ws + P->bn_prefix_off, P->bn_prefix.data(), P->bn_prefix.size() * sizeof(unsigned), hipMemcpyHostToDevice, E.st));
+    }
     P->pack_tab_ws = E.ws;
   }
   HIPCHK(launch_pack_all(P->dtype, E.params, E.ws, (const PackJob*)(E.ws + P->pack_tab_off),
@@ -559,6 +571,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
   int rc = pack_all_weights(E);
   if (rc) return rc;
   if (E.train) HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 64 * sizeof(unsigned), E.st));
+  // eval: the running statistics are all known up front -> scale/shift of every BatchNorm in ONE launch
+  // (a B=1 predict is launch-latency bound: 126 tiny kernels less per forward)
+  if (!E.train && !P->bn_jobs.empty())
+    HIPCHK(launch_bn_finalize_eval_all(E.params, E.buffers, E.ws, (const BnEvalJob*)(E.ws + P->bn_tab_off),
+                                       (const unsigned*)(E.ws + P->bn_prefix_off), (int)P->bn_jobs.size(), P->bn_total, 1e-5f, E.st));
   for (auto& op : P->ops) {
     switch (op.kind) {
       case OP_STEM_COL: {
@@ -598,9 +615,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
                                           E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f, 1e-5f, E.bn_scale(op.bn),
                                           E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), (double*)(E.ws + P->fin_part_off),
                                           (unsigned*)(E.ws + P->fin_cnt_off), E.st));
-        else
-          HIPCHK(launch_bn_finalize_eval(b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 1e-5f,
-                                         E.bn_scale(op.bn), E.bn_shift(op.bn), E.st));
+        // (eval: done for every BatchNorm at once in front of the loop)
         break;
       }
       case OP_BN_ACT: {
@@ -854,6 +869,7 @@ int octseg_plan_destroy(octseg_plan* p) {
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
   }
   delete p;
   return OCTSEG_OK;
@@ -938,7 +954,39 @@ int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void
   if (!p || !params || !buffers || !workspace || !image || !logits) return fail(OCTSEG_BAD_ARG, "null argument");
   if (normalize && (!mean || !stdv)) return fail(OCTSEG_BAD_ARG, "normalize=1 needs mean/std");
   Exec E{p, params, nullptr, buffers, (char*)workspace, (hipStream_t)stream, train};
-  return run_forward(E, image, logits, normalize, mean, stdv);
+  if (train || !p->graph_enabled) return run_forward(E, image, logits, normalize, mean, stdv);
+  // ---- eval forward through a hipGraph
+  octseg_plan::GraphKey key{params, buffers, workspace, image, logits, stream, normalize, {0, 0, 0}, {1, 1, 1}};
+  if (normalize) for (int i = 0; i < 3; ++i) { key.mean[i] = mean[i]; key.stdv[i] = stdv[i]; }
+  if (!(key == p->graph_key)) {   // new argument set: drop the old graph, start over with eager calls
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    p->graph_key = key; p->graph_seen = 0;
+  }
+  // weight images are packed outside the graph (a replay never repacks; octseg_plan_params_changed brings us here)
+  int rc = pack_all_weights(E);
+  if (rc) return rc;
+  if (p->graph_exec) { HIPCHK(hipGraphLaunch(p->graph_exec, E.st)); return OCTSEG_OK; }
+  if (p->graph_seen++ == 0) return run_forward(E, image, logits, normalize, mean, stdv);   // eager warm-up call
+  hipGraph_t g = nullptr;
+  HIPCHK(hipStreamBeginCapture(E.st, hipStreamCaptureModeThreadLocal));
+  rc = run_forward(E, image, logits, normalize, mean, stdv);
+  const hipError_t ce = hipStreamEndCapture(E.st, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (ce != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail(OCTSEG_HIP_ERROR, hipGetErrorString(ce)); }
+  const hipError_t ie = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie != hipSuccess) { p->graph_exec = nullptr; return fail(OCTSEG_HIP_ERROR, hipGetErrorString(ie)); }
+  HIPCHK(hipGraphLaunch(p->graph_exec, E.st));
+  return OCTSEG_OK;
+}
+
+// Eval-mode forwards of this plan are captured into a hipGraph and replayed while the argument set (pointers,
+// stream, normalisation constants) stays the same.  Training calls are never captured.
+int octseg_plan_set_graph(octseg_plan* p, int enable) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  p->graph_enabled = enable != 0;
+  if (!enable && p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; p->graph_seen = 0; }
+  return OCTSEG_OK;
 }
 
 int octseg_dice_forward(octseg_plan* p, void* workspace, const float* logits, const float* target, float* loss,

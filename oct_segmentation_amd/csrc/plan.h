@@ -101,6 +101,24 @@ struct octseg_plan {
   unsigned long long pack_total = 0;
   size_t pack_tab_off = 0, pack_prefix_off = 0;    // their place in the workspace
   const void* pack_tab_ws = nullptr;               // workspace the table was last uploaded to
+  std::vector<octseg::BnEvalJob> bn_jobs;          // eval: all BN scale/shift in one launch
+  std::vector<unsigned> bn_prefix;
+  unsigned bn_total = 0;
+  size_t bn_tab_off = 0, bn_prefix_off = 0;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // eval forward as a hipGraph (octseg_plan_set_graph): captured on the second call with an unchanged argument set,
+  // replayed while that set stays the same (a B=1 predict is ~400 launches of a few microseconds each)
+  bool graph_enabled = false;
+  int graph_seen = 0;                 // eager calls with the current key (the first sets the function attributes)
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    const void* params; const void* buffers; const void* ws; const void* image; const void* logits; const void* stream;
+    int normalize; float mean[3], stdv[3];
+    bool operator==(const GraphKey& o) const {
+      return params == o.params && buffers == o.buffers && ws == o.ws && image == o.image && logits == o.logits &&
+             stream == o.stream && normalize == o.normalize && mean[0] == o.mean[0] && mean[1] == o.mean[1] &&
+             mean[2] == o.mean[2] && stdv[0] == o.stdv[0] && stdv[1] == o.stdv[1] && stdv[2] == o.stdv[2];
+    }
+  } graph_key{};
 };

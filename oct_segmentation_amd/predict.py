@@ -25,7 +25,7 @@ MODELS_META = {
 }
 
 
-def load_model(model_dir, device='cuda', compute_dtype=torch.bfloat16):
+def load_model(model_dir, device='cuda', compute_dtype=torch.bfloat16, use_graph=False):
     """predict.py:31-50."""
     with open(os.path.join(model_dir, 'config.json')) as f:
         cfg = json.load(f)
@@ -34,6 +34,9 @@ def load_model(model_dir, device='cuda', compute_dtype=torch.bfloat16):
         encoder_name=cfg['encoder'], model_name=cfg['model_name'], in_channels=3, classes=cfg['classes'],
         map_location=device, compute_dtype=compute_dtype)
     model.eval()
+    # serving option: every eval forward of a (B, H, W) plan replays one captured hipGraph (bit-exact; measured no faster
+    # than the eager launches on MI355X -- 5.87 vs 5.74 ms at B=1 704x704 -- so it is off unless asked for)
+    model.model.use_graph = bool(use_graph)
     return model, cfg
 
 

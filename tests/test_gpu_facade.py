@@ -119,3 +119,34 @@ def test_segment_ensemble_channel_mapping(cuda, tmp_path):
     lc = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
     fc = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
     assert np.array_equal(out[0][:, :, 2], lc) and np.array_equal(out[0][:, :, 1], fc)
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager_forward(cuda):
+    """Serving path (predict.py / model.predict): eval forwards replayed from a captured hipGraph give the eager
+    logits bit for bit, for new frames and after the weights changed."""
+    import torch
+    from oct_segmentation_amd.engine import SegNet
+    net = SegNet('unetplusplus', 'resnet18', classes=2, device=cuda, compute_dtype=torch.bfloat16, seed=5).eval()
+    g = torch.Generator().manual_seed(11)
+    frames = [(torch.rand(2, 3, 64, 96, generator=g) * 255).to(cuda) for _ in range(4)]
+    mean, std = [123.7, 116.3, 103.5], [58.4, 57.1, 57.4]
+    eager = [net(f, normalize=True, mean=mean, std=std).clone() for f in frames]
+    net.use_graph = True
+    for rep in range(2):                      # call 1 eager warm-up, call 2 capture, then replays
+        for f, e in zip(frames, eager):
+            assert torch.equal(net(f, normalize=True, mean=mean, std=std), e)
+    # weights change in place -> images repacked outside the graph, same graph replayed
+    with torch.no_grad():
+        net.arena.mul_(0.5)
+    net.use_graph = False
+    e2 = net(frames[0], normalize=True, mean=mean, std=std).clone()
+    net.use_graph = True
+    assert torch.equal(net(frames[0], normalize=True, mean=mean, std=std), e2)
+    assert not torch.equal(e2, eager[0])
+    # other normalisation constants -> new capture, still exact
+    net.use_graph = False
+    e3 = net(frames[1], normalize=False).clone()
+    net.use_graph = True
+    for _ in range(3):
+        assert torch.equal(net(frames[1], normalize=False), e3)
