@@ -16,6 +16,9 @@
 #include "conv_common.h"
 #include "kernels.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace octseg {
 
 #ifdef OCTSEG_STAMP
@@ -231,6 +234,132 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
       for (int u = 0; u < MAXW; ++u) sg.write(ldsX, min(u, npw - 1), xv[u], xok[u]);
     };
     int tile = blockIdx.z;
+    if constexpr (sizeof(T) == 2) {
+      if (pipelined == 2 && tile < ntiles) {
+        // Two LDS tile buffers, ONE barrier per tile, and nothing but MFMAs on the critical path: while the 8 pixel rows
+        // of tile k are contracted out of buffer k&1, the register-held loads of tile k+1 are stored into the other
+        // buffer (rows 0-3) and the global loads of tile k+2 are issued into the same registers (rows 4-7), all as
+        // fillers in the MFMA gaps (the wave is alone on its SIMD: a separate issue / store phase idles the pipe).
+        constexpr int TH8 = 8, NSLOT = TH8 * NTAPS, NITEM = MAXY + MAXW;
+        const int tile_bytes = (npy + npw) * PSTEP * PITCH;
+        struct Pair { s16x4_t lo, hi; };
+        struct Frags { uint4 y; uint4 x[NTAPS]; };
+        TilePos tp2{0, 0, 0};
+        const char* yb2 = nullptr;
+        int gy02 = 0, gx02 = 0;
+        auto item = [&](auto jc, auto phase, char* oy, char* ox) __attribute__((always_inline)) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int PH = decltype(phase)::value;
+          if constexpr (PH == 0) {            // store pass J of the tile held in registers
+            if constexpr (J < MAXY) *(uint4*)(oy + (min(J, npy - 1) * PSTEP + yp0) * PITCH + ycv * 16) = yok[J] ? yv[J] : make_uint4(0, 0, 0, 0);
+            else sg.write(ox, min(J - MAXY, npw - 1), xv[J - MAXY], xok[J - MAXY]);
+          } else {                            // load pass J of the tile after next
+            if constexpr (J < MAXY) yv[J] = load_y(yb2, tp2, ypos[J] >> 16, ypos[J] & 0xffff, yin[J], yok[J]);
+            else xv[J - MAXY] = sg.load_at(wpos[J - MAXY] >> 16, wpos[J - MAXY] & 0xffff, win[J - MAXY], gy02, gx02, smul, a.IH, a.IW, xok[J - MAXY]);
+          }
+        };
+        // filler slot S of the tile (one per MFMA): the items whose share of the half tile falls on it
+        auto fillers = [&](auto sc_, char* oy, char* ox) __attribute__((always_inline)) {
+          constexpr int S = decltype(sc_)::value;
+          constexpr int HALF = NSLOT / 2;
+          constexpr int PH = S < HALF ? 0 : 1;
+          constexpr int SS = S - PH * HALF;
+          constexpr int J0 = (SS * NITEM + HALF - 1) / HALF, J1 = ((SS + 1) * NITEM + HALF - 1) / HALF;   // ceil ranges
+          if constexpr (J0 < J1 && J0 < NITEM) item(std::integral_constant<int, J0>{}, std::integral_constant<int, PH>{}, oy, ox);
+          if constexpr (J0 + 1 < J1 && J0 + 1 < NITEM) item(std::integral_constant<int, J0 + 1>{}, std::integral_constant<int, PH>{}, oy, ox);
+          if constexpr (J0 + 2 < J1 && J0 + 2 < NITEM) item(std::integral_constant<int, J0 + 2>{}, std::integral_constant<int, PH>{}, oy, ox);
+        };
+        auto load_y1 = [&](const char* by, int kk, Frags& f) __attribute__((always_inline)) {
+          const char* yrow = by + kk * TW * PITCH + ya0;
+          Pair ya;
+          ya.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
+          ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
+          f.y = __builtin_bit_cast(uint4, ya);
+        };
+        auto load_x1 = [&](const char* xrow, int t, Frags& f) __attribute__((always_inline)) {
+          Pair xb;
+          xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
+          xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
+          f.x[t] = __builtin_bit_cast(uint4, xb);
+        };
+        auto row = [&](auto kc, const Frags& cur, Frags& nxt, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
+          constexpr int KK = decltype(kc)::value;
+          constexpr int KN = KK + 1 < TH8 ? KK + 1 : TH8 - 1;
+          const char* xrow = bx + (KN * lstride) * RW * PITCH + xa0;
+#pragma unroll
+          for (int t = 0; t < NTAPS; ++t) {
+            Tr<T>::mma(cur.y, cur.x[t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (KK + 1 < TH8) {
+              if (t == 0) load_y1(by, KN, nxt);
+              load_x1(xrow, t, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        // the filler of slot KK*NTAPS + t sits behind MFMA t of row KK: expanded per row with constant indices
+        auto row_f = [&](auto kc, const Frags& cur, Frags& nxt, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
+          constexpr int KK = decltype(kc)::value;
+          constexpr int KN = KK + 1 < TH8 ? KK + 1 : TH8 - 1;
+          const char* xrow = bx + (KN * lstride) * RW * PITCH + xa0;
+          auto one = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < NTAPS) {
+              Tr<T>::mma(cur.y, cur.x[t], acc[t]);
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (KK + 1 < TH8) {
+                if constexpr (t == 0) load_y1(by, KN, nxt);
+                load_x1(xrow, t, nxt);
+              }
+              fillers(std::integral_constant<int, KK * NTAPS + t>{}, oy, ox);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+          one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+          one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
+        };
+        (void)row;
+        // prologue: tile 0 into buffer 0, tile 1 into the registers
+        load_tile(tile);
+        write_tile();
+        load_tile(tile + a.ksplit < ntiles ? tile + a.ksplit : tile);
+        __syncthreads();
+        int cur = 0;
+        for (; tile < ntiles; tile += a.ksplit) {
+          const int t2 = tile + 2 * a.ksplit < ntiles ? tile + 2 * a.ksplit : tile;   // clamped: a re-fetch at the tail is harmless
+          tp2 = tile_pos(t2);
+          yb2 = y_base(tp2.n);
+          gy02 = tp2.y0 * a.istride + a.min_dy; gx02 = tp2.x0 * a.istride + a.min_dx;
+          const char* by = smem + cur * tile_bytes;
+          const char* bx = by + npy * PSTEP * PITCH;
+          char* oy = smem + (cur ^ 1) * tile_bytes;
+          char* ox = oy + npy * PSTEP * PITCH;
+          Frags fa, fb;
+          {
+            const char* xrow0 = bx + xa0;
+            load_y1(by, 0, fa);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) load_x1(xrow0, t, fa);
+          }
+          // loads of tile k+2 address the image through sg: bind it once the stores of tile k+1 (which only need
+          // scale / shift) are past -- the first load item sits in the second half of the tile
+          row_f(std::integral_constant<int, 0>{}, fa, fb, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 1>{}, fb, fa, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 2>{}, fa, fb, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 3>{}, fb, fa, by, bx, oy, ox);
+          sg.bind_image(tp2.n);
+          row_f(std::integral_constant<int, 4>{}, fa, fb, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 5>{}, fb, fa, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 6>{}, fa, fb, by, bx, oy, ox);
+          row_f(std::integral_constant<int, 7>{}, fb, fa, by, bx, oy, ox);
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          cur ^= 1;
+        }
+        tile = ntiles;   // done: skip the single-buffer loop below
+      }
+    }
     if (tile < ntiles) {
       load_tile(tile);
       write_tile();
@@ -325,7 +454,10 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
     th = 8;
     while (th > 1 && wgrad_geom(a, dtype, th).lds > 150 * 1024) th >>= 1;
   }
-  const size_t lds = wgrad_geom(a, dtype, th).lds;
+  size_t lds = wgrad_geom(a, dtype, th).lds;
+  // bf16, 8-row tiles, 3x3: double-buffered tiles with the stores / loads as MFMA fillers (one barrier per tile)
+  static const bool no_pipe2 = getenv("OCTSEG_NO_WGRAD_PIPE2") != nullptr;
+  if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && NTAPS == 9 && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
   int ks = 512 / (gx * gy);  // one resident round at most (two workgroup slots per CU): 516 workgroups take twice as long as 504
