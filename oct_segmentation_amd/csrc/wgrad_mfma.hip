@@ -276,32 +276,23 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
           f.y = __builtin_bit_cast(uint4, ya);
         };
-        auto load_x1 = [&](const char* xrow, int t, Frags& f) __attribute__((always_inline)) {
+        // this path is only taken for the standard 3x3 stride-1 tap table (host-checked): window rows are 18 pixels and
+        // tap t sits (t / 3) rows and (t % 3) pixels in, so every fragment address is one per-tile base register plus
+        // an immediate offset -- no address arithmetic in the MFMA gaps (the wave is alone on its SIMD: every
+        // instruction beside the MFMAs costs issue cycles nobody hides)
+        auto load_x1 = [&](const char* xbase, auto knc, auto tc, Frags& f) __attribute__((always_inline)) {
+          constexpr int KNR = decltype(knc)::value, t = decltype(tc)::value;
+          constexpr int OFF = ((KNR + t / 3) * 18 + t % 3) * PITCH;
           Pair xb;
-          xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t]));
-          xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xrow + toff[t] + xrow_step));
+          xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
+          xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF + 4 * PITCH));
           f.x[t] = __builtin_bit_cast(uint4, xb);
-        };
-        auto row = [&](auto kc, const Frags& cur, Frags& nxt, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
-          constexpr int KK = decltype(kc)::value;
-          constexpr int KN = KK + 1 < TH8 ? KK + 1 : TH8 - 1;
-          const char* xrow = bx + (KN * lstride) * RW * PITCH + xa0;
-#pragma unroll
-          for (int t = 0; t < NTAPS; ++t) {
-            Tr<T>::mma(cur.y, cur.x[t], acc[t]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (KK + 1 < TH8) {
-              if (t == 0) load_y1(by, KN, nxt);
-              load_x1(xrow, t, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
         };
         // the filler of slot KK*NTAPS + t sits behind MFMA t of row KK: expanded per row with constant indices
         auto row_f = [&](auto kc, const Frags& cur, Frags& nxt, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
           constexpr int KK = decltype(kc)::value;
           constexpr int KN = KK + 1 < TH8 ? KK + 1 : TH8 - 1;
-          const char* xrow = bx + (KN * lstride) * RW * PITCH + xa0;
+          const char* xbase = bx + xa0;
           auto one = [&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < NTAPS) {
@@ -309,7 +300,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (KK + 1 < TH8) {
                 if constexpr (t == 0) load_y1(by, KN, nxt);
-                load_x1(xrow, t, nxt);
+                load_x1(xbase, std::integral_constant<int, KN>{}, tc, nxt);
               }
               fillers(std::integral_constant<int, KK * NTAPS + t>{}, oy, ox);
               __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +310,6 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
           one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
         };
-        (void)row;
         // prologue: tile 0 into buffer 0, tile 1 into the registers
         load_tile(tile);
         write_tile();
@@ -337,10 +327,16 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           char* ox = oy + npy * PSTEP * PITCH;
           Frags fa, fb;
           {
-            const char* xrow0 = bx + xa0;
+            const char* xbase = bx + xa0;
+            auto z = std::integral_constant<int, 0>{};
             load_y1(by, 0, fa);
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) load_x1(xrow0, t, fa);
+            load_x1(xbase, z, std::integral_constant<int, 0>{}, fa); load_x1(xbase, z, std::integral_constant<int, 1>{}, fa);
+            load_x1(xbase, z, std::integral_constant<int, 2>{}, fa);
+            if constexpr (NTAPS == 9) {
+              load_x1(xbase, z, std::integral_constant<int, 3>{}, fa); load_x1(xbase, z, std::integral_constant<int, 4>{}, fa);
+              load_x1(xbase, z, std::integral_constant<int, 5>{}, fa); load_x1(xbase, z, std::integral_constant<int, 6>{}, fa);
+              load_x1(xbase, z, std::integral_constant<int, 7>{}, fa); load_x1(xbase, z, std::integral_constant<int, 8>{}, fa);
+            }
           }
           // loads of tile k+2 address the image through sg: bind it once the stores of tile k+1 (which only need
           // scale / shift) are past -- the first load item sits in the second half of the tile
@@ -457,7 +453,9 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   size_t lds = wgrad_geom(a, dtype, th).lds;
   // bf16, 8-row tiles, 3x3: double-buffered tiles with the stores / loads as MFMA fillers (one barrier per tile)
   static const bool no_pipe2 = getenv("OCTSEG_NO_WGRAD_PIPE2") != nullptr;
-  if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && NTAPS == 9 && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
+  bool std33 = NTAPS == 9 && a.istride == 1 && a.span_x == 3 && a.span_y == 3;
+  for (int t = 0; std33 && t < 9; ++t) std33 = a.tap_dy[t] - a.min_dy == t / 3 && a.tap_dx[t] - a.min_dx == t % 3;
+  if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && std33 && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
   int ks = 512 / (gx * gy);  // one resident round at most (two workgroup slots per CU): 516 workgroups take twice as long as 504
