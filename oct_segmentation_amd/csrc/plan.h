@@ -67,6 +67,7 @@ struct Op {
   int post = -1;
   bool relu = true;
   int in = -1, out = -1;  // OP_MAXPOOL / OP_BN_ACT / OP_STEM_COL out
+  int lane = 0;           // forward stream: 0 main, 1 side (decoder nodes that only need early encoder features)
 };
 
 }  // namespace octseg
@@ -82,7 +83,8 @@ struct octseg_plan {
   size_t param_numel = 0, buffer_numel = 0;
   size_t ws_bytes = 0;
   size_t act_begin = 0, act_end = 0, grad_begin = 0, grad_end = 0;
-  size_t slab_off = 0, slab_bytes = 0;       // BN partial-sum slab (shared, reused per layer)
+  size_t slab_off = 0, slab_bytes = 0;       // BN partial-sum slab (reused per layer; one per forward lane)
+  bool has_lanes = false;
   size_t fin_part_off = 0, fin_cnt_off = 0;  // scratch of the two-level slab reduction (BN finalize)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits

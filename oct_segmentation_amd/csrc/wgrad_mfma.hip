@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
       for (int u = 0; u < MAXW; ++u) sg.write(ldsX, min(u, npw - 1), xv[u], xok[u]);
     };
     int tile = blockIdx.z;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && NTAPS == 9) {
       if (pipelined == 2 && tile < ntiles) {
         // Two LDS tile buffers, ONE barrier per tile, and nothing but MFMAs on the critical path: while the 8 pixel rows
         // of tile k are contracted out of buffer k&1, the register-held loads of tile k+1 are stored into the other
