@@ -34,6 +34,8 @@ struct DstDesc {
   int cn;     // number of channels
   int H, W;   // full spatial size of the destination tensor
   int accum;  // 1: add to what is there (a later gradient contribution), 0: plain store (first writer)
+  int pool;   // 1: the destination is the half-resolution tensor behind a nearest-x2 upsample: every 2x2 output quad is
+              //    summed in the epilogue (H, W are then the half-resolution extents; ostride must be 1)
 };
 
 enum OutMode { OUT_STORE = 0, OUT_ACCUM = 1, OUT_HEAD_NCHW = 2 };

@@ -161,11 +161,46 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       const int cov = co0 + cvv * VEC;                      // this thread's channel vector: the same in every sweep
       if (cov >= a.Cout) return;
       char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W, dacc = a.dst[0].accum;
+      int dpool = a.dst[0].pool;
 #pragma unroll
       for (int i = 1; i < MAX_SRC; ++i)
         if (i < a.ndst && cov >= a.dst[i].c0) {
           dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W; dacc = a.dst[i].accum;
+          dpool = a.dst[i].pool;
         }
+      if (dpool) {
+        // gradient of a nearest-x2 upsample: sum each 2x2 quad of the tile (T-rounded values, f32 sum, one rounding:
+        // bit for bit what pool2x2_accum over a T temp gives) and store / accumulate at half resolution
+        for (int k = 0; k < BM / PPI; ++k) {
+          const int pp = p + k * PPI;
+          const int ty = pp >> 4, tx = pp & 15;
+          if ((ty | tx) & 1) continue;
+          const char* l0 = otile + pp * OPITCH + cvv * 16;
+          const uint4 q[4] = {*(const uint4*)l0, *(const uint4*)(l0 + OPITCH), *(const uint4*)(l0 + TW * OPITCH),
+                              *(const uint4*)(l0 + (TW + 1) * OPITCH)};
+          uint4* gq = (uint4*)(dptr + ((((size_t)n * dH + ((y0 + ty) >> 1)) * dW + ((x0 + tx) >> 1)) * dC + (cov - dc0)) * ES);
+          uint4 old = make_uint4(0, 0, 0, 0);
+          if (dacc) old = *gq;
+          unsigned o[4] = {old.x, old.y, old.z, old.w}, r4[4];
+          const unsigned* qq[4] = {&q[0].x, &q[1].x, &q[2].x, &q[3].x};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {   // old + q00 + q01 + q10 + q11 in f32, one rounding (the order of pool2x2_accum)
+            if (sizeof(T) == 4) {
+              float sacc = dacc ? __uint_as_float(o[i]) : 0.f;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sacc += __uint_as_float(qq[j][i]);
+              r4[i] = __float_as_uint(sacc);
+            } else {
+              float lo = dacc ? __uint_as_float(o[i] << 16) : 0.f, hi = dacc ? __uint_as_float(o[i] & 0xffff0000u) : 0.f;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { lo += __uint_as_float(qq[j][i] << 16); hi += __uint_as_float(qq[j][i] & 0xffff0000u); }
+              r4[i] = pack_bf16(lo, hi);
+            }
+          }
+          *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        }
+        return;
+      }
       const size_t pixb = (size_t)dC * ES * a.ostride;      // bytes between horizontally adjacent outputs
       const size_t rowb = (size_t)dW * dC * ES * a.ostride;
       const int oy = (y0 + (p >> 4)) * a.ostride + a.ooy, ox = (x0 + (p & 15)) * a.ostride + a.oox;
@@ -272,11 +307,41 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       const int co = co0 + cvv * VEC;
       if (gy >= a.OH || gx >= a.OW || co >= a.Cout) continue;
       char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W, dacc = a.dst[0].accum;
+      int dpool = a.dst[0].pool;
 #pragma unroll
       for (int i = 1; i < MAX_SRC; ++i)
         if (i < a.ndst && co >= a.dst[i].c0) {
           dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W; dacc = a.dst[i].accum;
+          dpool = a.dst[i].pool;
         }
+      if (dpool) {   // 2x2 quad sum into the half-resolution destination (tile origins and extents are even: a quad is
+                     // inside the image as a whole or not at all)
+        if ((ty | tx) & 1) continue;
+        const char* l0 = otile + p * OPITCH + cvv * 16;
+        const uint4 q[4] = {*(const uint4*)l0, *(const uint4*)(l0 + OPITCH), *(const uint4*)(l0 + TW * OPITCH),
+                            *(const uint4*)(l0 + (TW + 1) * OPITCH)};
+        uint4* gq = (uint4*)(dptr + ((((size_t)n * dH + (gy >> 1)) * dW + (gx >> 1)) * dC + (co - dc0)) * sizeof(T));
+        uint4 old = make_uint4(0, 0, 0, 0);
+        if (dacc) old = *gq;
+        unsigned o[4] = {old.x, old.y, old.z, old.w}, r4[4];
+        const unsigned* qq[4] = {&q[0].x, &q[1].x, &q[2].x, &q[3].x};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (sizeof(T) == 4) {
+            float sacc = dacc ? __uint_as_float(o[i]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc += __uint_as_float(qq[j][i]);
+            r4[i] = __float_as_uint(sacc);
+          } else {
+            float lo = dacc ? __uint_as_float(o[i] << 16) : 0.f, hi = dacc ? __uint_as_float(o[i] & 0xffff0000u) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lo += __uint_as_float(qq[j][i] << 16); hi += __uint_as_float(qq[j][i] & 0xffff0000u); }
+            r4[i] = pack_bf16(lo, hi);
+          }
+        }
+        *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        continue;
+      }
       const int oy = gy * a.ostride + a.ooy, ox = gx * a.ostride + a.oox;
       uint4* gp = (uint4*)(dptr + ((((size_t)n * dH + oy) * dW + ox) * dC + (co - dc0)) * sizeof(T));
       uint4 val = *(const uint4*)(otile + p * OPITCH + cvv * 16);
@@ -632,30 +697,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
           },
           [&]() {   // behind k-step 1: everything the previous tap issued has landed (this tap's DPW + W operations
                     // may fly): the slab of the next tap, and the slice loaded one tap ago -> lazy BN / ReLU on it
+            STAMP(s2);
             if constexpr (TT >= 1) {
               if constexpr ((TT - 1) & 1) {
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(avB) : "n"(DPW + W) : "memory");
+                STAMP(s3);
                 wv = nxt.prep(__builtin_bit_cast(uint4, avB), okB);
               } else {
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(avA) : "n"(DPW + W) : "memory");
+                STAMP(s3);
                 wv = nxt.prep(__builtin_bit_cast(uint4, avA), okA);
               }
             } else {
               asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + W) : "memory");
+              STAMP(s3);
             }
+#ifdef OCTSEG_STAMP
+            tsum[2] += s3 - s2;
+#endif
           },
           [&]() {   // behind k-step 2: its LDS store
             if constexpr (TT >= 1) *(uint4*)((((TT - 1) & 1) ? wrB : wrA) + nxt.cv * 16) = wv;
           });
         __builtin_amdgcn_sched_barrier(0);
-        STAMP(s2);
+        unsigned long long s2e = 0; (void)s2e;
+        STAMP(s2e);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STAMP(s4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         STAMP(s5);
 #ifdef OCTSEG_STAMP
-        tsum[0] += s1 - s0; tsum[1] += s2 - s1; tsum[3] += s4 - s2; tsum[4] += s5 - s4; tsum[5] += 1;
+        tsum[0] += s1 - s0; tsum[1] += s2e - s1; tsum[3] += s4 - s2e; tsum[4] += s5 - s4; tsum[5] += 1;
 #endif
         if (++tap2 == 9) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
         ++it;

@@ -705,7 +705,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
           a.ndst = 1;
           DstDesc d;
-          d.accum = 0;
+          d.accum = 0; d.pool = 0;
           if (L.head) { d.ptr = logits; d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW; }
           else { d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE; }
           a.dst[0] = d;
@@ -842,8 +842,13 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     const int ti = L.srcs[i].v.t;
     const TensorInfo& t = P->tensors[ti];
     DstDesc d;
-    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = 0;
-    if (L.srcs[i].up) {
+    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = 0; d.pool = 0;
+    static const bool no_fuse_pool = getenv("OCTSEG_NO_FUSED_POOL") != nullptr;
+    if (L.srcs[i].up && t.need_grad && !no_fuse_pool && ld.size() == 1 && ld[0].ostride == 1 && (L.IH % 2) == 0 && (L.IW % 2) == 0) {
+      // gradient of the nearest-x2 upsample: the dgrad epilogue sums the 2x2 quads straight into the source's gradient
+      d.ptr = E.grad(ti); d.H = t.H; d.W = t.W; d.pool = 1;
+      d.accum = E.claim(ti);
+    } else if (L.srcs[i].up) {
       d.ptr = E.ws + P->tmp_off;     // fully covered by this dgrad, pooled into the source afterwards
       up_src = (int)i;
     } else if (!t.need_grad) {
@@ -1186,7 +1191,7 @@ int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float*
   for (auto& a : la) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.W = scratch; a.bias = bias;
-    DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW; d.accum = 0;
+    DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW; d.accum = 0; d.pool = 0;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr; a.stamp = g_stamp;
     HIPCHK(launch_conv(dtype, a, st));
   }
@@ -1211,7 +1216,7 @@ int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void*
   for (auto& a : ld) {
     SrcDesc s; s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = Cout; s.c0 = 0; s.H = g.OH; s.W = g.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = scratch; a.bias = nullptr;
-    DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W; d.accum = 1;
+    DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W; d.accum = 1; d.pool = 0;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_ACCUM; a.stat_slab = nullptr;
     HIPCHK(launch_conv(dtype, a, st));
   }
