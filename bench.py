@@ -13,8 +13,10 @@ per-GPU batch stays 16, so scaling is "weak".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline      -- the MFMA conv kernels (conv_mfma_kernel + wgrad_mfma_kernel), timed live with HIP
-                   events on the launch stream over the timed steps: algorithmic conv FLOPs
-                   (6 * MACs * frames) / summed kernel time, vs 2.5 PFLOP/s dense bf16
+                   events on the launch stream: algorithmic conv FLOPs (6 * MACs * frames, SURVEY.md
+                   section 8d) / summed kernel time, vs 2.5 PFLOP/s dense bf16.  `achieved` comes from an
+                   untimed extra pass with every launch on one stream (kernels alone); the brackets of the
+                   timed, stream-overlapped steps are reported beside it under `overlapped`
   cpu_baseline  -- the torch-CPU oracle (a port, not the reference's own files) on one 704x704
                    frame of the same workload, fp32, all host cores
 """
@@ -160,6 +162,20 @@ def main():
     prof = (C.c_double * 9)()
     L.check(L.lib().octseg_profile_stop(prof))
     loss_val = float(loss.item())
+    # Roofline pass (untimed, after the measured steps): the same step with every launch on one stream, so that the
+    # HIP-event bracket of a launch is the duration of that kernel alone.  In the timed steps the weight gradients and
+    # part of the decoder run on a side stream; brackets taken there also contain the time a kernel shares the chip.
+    prof_alone = (C.c_double * 9)()
+    n_alone = 2
+    L.check(L.lib().octseg_debug_set_serial(1))
+    step()
+    barrier()
+    L.check(L.lib().octseg_profile_start())
+    for _ in range(n_alone):
+        step()
+    barrier()
+    L.check(L.lib().octseg_profile_stop(prof_alone))
+    L.check(L.lib().octseg_debug_set_serial(0))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -168,9 +184,11 @@ def main():
     if rank == 0:
         frames = world * B * args.steps
         macs = net.fwd_macs(B, S, S) / B  # per frame
-        ms = [prof[0], prof[3], prof[6]]
-        fl = [prof[1], prof[4], prof[7]]
-        nl = [prof[2], prof[5], prof[8]]
+        oms = [prof[0], prof[3], prof[6]]          # overlapped (timed) steps
+        ofl = [prof[1], prof[4], prof[7]]
+        ms = [prof_alone[0], prof_alone[3], prof_alone[6]]   # kernels alone (roofline pass)
+        fl = [prof_alone[1], prof_alone[4], prof_alone[7]]
+        nl = [prof_alone[2], prof_alone[5], prof_alone[8]]
         tot_ms, tot_fl = sum(ms), sum(fl)
         peak = 2500.0 if args.dtype == 'bf16' else 157.3
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
@@ -193,13 +211,23 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
-                'launches_per_step': round(sum(nl) / args.steps, 1),
+                'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
-                'kernel_ms_per_step': round(tot_ms / args.steps, 3),
-                'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
+                'kernel_ms_per_step': round(tot_ms / n_alone, 3),
+                'by_class': {k: {'ms_per_step': round(m / n_alone, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
                              for k, m, f in zip(('fwd', 'dgrad', 'wgrad'), ms, fl)},
                 'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
-                'note': 'durations are HIP-event brackets on each launch stream; weight gradients run on a side stream beside the dgrad/BN chain, so the class sums overlap in wall time',
+                'note': 'HIP-event brackets on the launch stream over an untimed pass of the same step with every launch on one '
+                        'stream (octseg_debug_set_serial): the duration of each kernel alone; rocprofv3 summary of that mode: '
+                        'profiles/r1_serial_kernel_stats.csv',
+                'overlapped': {
+                    'note': 'the same brackets during the TIMED steps, where weight gradients and part of the decoder run on a '
+                            'side stream: durations include the time a kernel shares the chip (profiles/r1_r_bench_kernel_stats.csv)',
+                    'kernel_ms_per_step': round(sum(oms) / args.steps, 3),
+                    'achieved': round(sum(ofl) / (sum(oms) * 1e-3) / 1e12, 2) if sum(oms) > 0 else 0.0,
+                    'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
+                                 for k, m, f in zip(('fwd', 'dgrad', 'wgrad'), oms, ofl)},
+                },
             },
         }
         # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)

@@ -135,6 +135,9 @@ int octseg_optim_step(int kind, float* params, const float* grads, float* state_
 /* diagnostic hook: with a library built with -DOCTSEG_STAMP, octseg_conv2d_forward adds per-phase cycle
  * sums of the tap loop into dev_buf[6] (u64, device); a no-op in the shipped build. */
 int octseg_debug_set_stamp(unsigned long long* dev_buf);
+/* Measurement aid: on = 1 runs every launch of forward and backward on the caller's stream, one after the other
+ * (no forward lanes, no weight-gradient side stream), so that per-kernel durations are those of the kernels alone. */
+int octseg_debug_set_serial(int on);
 
 /* ---- single-op entry points (NHWC device tensors of `dtype`; weights fp32 in arena layout) ---- */
 /* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w[R][S][Cout][Cin]) (+bias);  transposed=1: ConvTranspose2d

@@ -58,6 +58,7 @@ SYMBOLS = {
     'octseg_net_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P]),
     'octseg_optim_step': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
     'octseg_debug_set_stamp': (C.c_int, [_P]),
+    'octseg_debug_set_serial': (C.c_int, [C.c_int]),
     'octseg_conv2d_scratch_bytes': (C.c_size_t, [C.c_int] * 8),
     'octseg_conv2d_forward': (C.c_int, [C.c_int, _P, _P, _P, _P] + [C.c_int] * 10 + [_P, _P]),
     'octseg_conv2d_backward_data': (C.c_int, [C.c_int, _P, _P, _P] + [C.c_int] * 10 + [_P, _P]),

@@ -190,6 +190,8 @@ static void wgrad_launches(const Geom& g, std::vector<WgradArgs>& out) {
 }
 
 // ================================================================ graph builder
+static bool serial_mode();
+
 namespace {
 
 struct Builder {
@@ -649,7 +651,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
   // ---- forward lanes (assign_lanes): lane-1 ops go to the side stream; a lane waits for the other one only when it
   // reads something the other lane produced and has not synchronised with since
   static const bool no_lanes = getenv("OCTSEG_NO_FWD_LANES") != nullptr;
-  const bool lanes = P->has_lanes && !no_lanes;
+  const bool lanes = P->has_lanes && !no_lanes && !serial_mode();
   hipStream_t lst[2] = {E.st, E.st};
   if (lanes) {
     if (!P->side) {
@@ -891,7 +893,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
   HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 2 * 64 * sizeof(unsigned), E.st));
   E.ginit.assign(P->tensors.size(), 0);
-  if (!getenv("OCTSEG_NO_SIDE_STREAM")) {
+  if (!getenv("OCTSEG_NO_SIDE_STREAM") && !serial_mode()) {
     if (!P->side) {
       HIPCHK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
@@ -1162,8 +1164,10 @@ static bool geom_ok(int dtype, int Cin, int Cout, int R, int S, int stride, int 
   return true;
 }
 static unsigned long long* g_stamp = nullptr;
+static bool g_serial = false;   // octseg_debug_set_serial: one stream, no lanes (isolated kernel durations)
 // diagnostic builds only (-DOCTSEG_STAMP): device buffer of 6 u64 receiving the per-phase cycle sums
 int octseg_debug_set_stamp(unsigned long long* dev_buf) { g_stamp = dev_buf; return OCTSEG_OK; }
+int octseg_debug_set_serial(int on) { g_serial = on != 0; return OCTSEG_OK; }
 
 static Geom op_geom(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int transposed) {
   Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
@@ -1242,3 +1246,5 @@ int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, floa
 }
 
 }  // extern "C"
+
+static bool serial_mode() { return g_serial; }
