@@ -644,8 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   auto run9r = [&]() __attribute__((always_inline)) {
     constexpr int D = 3;
-    int it = 0;
-    int tap2 = D - 1, chunk2 = 0;                   // slab cursor: iteration it + D - 1
+    int tap2 = D - 1, chunk2 = 0;                   // slab cursor: two iterations ahead
     int slotC = 0, slotS = D - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool has_next = chunk + 1 < nchunks;
@@ -672,20 +671,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
         STAMP(s1);
         mma_tap_f(awin, bsl, toff,
           [&]() {   // behind k-step 0: this tap's prefetches (slab of iteration it + 2 first, then the slice)
-#ifndef OCTSEG_EXP_NOSLAB   // timing experiments only
             dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, slotS);
-#endif
             if (++slotS == D) slotS = 0;
             if constexpr (TT < 8) {
               bool& ok = (TT & 1) ? okB : okA;
               char*& wr = (TT & 1) ? wrB : wrA;
               const char* g = nxt.addr_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok);
-#ifndef OCTSEG_EXP_NOSLICE
               if constexpr (TT & 1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(avB) : "v"(g));
               else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(avA) : "v"(g));
-#else
-              (void)g;
-#endif
               wr = wrow;
               const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
               if (adv) {
@@ -731,7 +724,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
         tsum[0] += s1 - s0; tsum[1] += s2e - s1; tsum[3] += s4 - s2e; tsum[4] += s5 - s4; tsum[5] += 1;
 #endif
         if (++tap2 == 9) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
-        ++it;
       };
       tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
       tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
@@ -757,17 +749,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
 #endif
 
-  if (mode & 4) {   // timing experiment only (OCTSEG_SKIP_EPILOGUE): one store per thread keeps the accumulators live
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += acc[i][j][k];
-    if (t == 123.456f) ((float*)a.dst[0].ptr)[0] = t;
-    return;
-  }
   conv_epilogue<T, NT, WN, WM, false>(a, smem, acc, tp);
 }
 
@@ -1237,7 +1218,8 @@ Choice choose(const ConvArgs& a, int esz) {
     return (double)a.OH * a.OW / (ty * TH * tx * TW);
   };
   int wm_first = util(8) > 1.15 * util(16) ? 2 : 4;
-  if (getenv("OCTSEG_FORCE_WM")) wm_first = atoi(getenv("OCTSEG_FORCE_WM"));   // experiments only
+  static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch
+  if (force_wm) wm_first = force_wm;
   const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};
   static const int force_d = getenv("OCTSEG_PIPE_D") ? atoi(getenv("OCTSEG_PIPE_D")) : 0;   // experiments only
   for (int D = force_d ? force_d : 4; D >= (force_d ? force_d : 3); --D)
@@ -1246,7 +1228,6 @@ Choice choose(const ConvArgs& a, int esz) {
       const size_t lds = pipe_lds(a, v, esz, D);
       if (lds != 0 && lds <= 160 * 1024) {
         c.v = v; c.dbuf = 1; c.lds = lds; c.resident = 0; c.pipe = D;
-        if (getenv("OCTSEG_PIPE_LDS")) c.lds = (size_t)atoi(getenv("OCTSEG_PIPE_LDS"));   // experiments only
         return c;
       }
     }
@@ -1273,7 +1254,8 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
     const int kc = (a.Cin <= (128 / esz) / 2 ? 64 : 128) / esz;
     if (a.ntaps == 1 || a.Cin <= kc) wm_first = 2;
   }
-  if (getenv("OCTSEG_FORCE_WM")) wm_first = atoi(getenv("OCTSEG_FORCE_WM"));   // experiments only
+  static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch
+  if (force_wm) wm_first = force_wm;
   const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};
   const int nchunks_c = (a.Cin + RB / esz - 1) / (RB / esz);
   // a single K chunk never restages its window: a second buffer would only cost occupancy
@@ -1323,9 +1305,10 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
 #undef OCTSEG_PIPE
     return hipErrorInvalidValue;
   }
+  static const bool no_run9 = getenv("OCTSEG_NO_RUN9") != nullptr;   // A/B switch: the rolled tap loop instead of run9r
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (getenv("OCTSEG_SKIP_EPILOGUE") ? 4 : 0) | (getenv("OCTSEG_NO_RUN9") ? 8 : 0) | (c.ring3 ? 16 : 0), c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (no_run9 ? 8 : 0) | (c.ring3 ? 16 : 0), c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)

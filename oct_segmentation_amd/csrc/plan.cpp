@@ -821,8 +821,6 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.dW = E.grads + P->params[L.w].off;
       a.stamp = nullptr;
       ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), ws_, L.name);
-      static const bool skip_wgrad = getenv("OCTSEG_EXP_SKIP_WGRAD") != nullptr;   // timing experiment only
-      if (skip_wgrad) continue;
       HIPCHK(launch_wgrad(P->dtype, a, ws_));
     }
   }
@@ -893,7 +891,8 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
   HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 2 * 64 * sizeof(unsigned), E.st));
   E.ginit.assign(P->tensors.size(), 0);
-  if (!getenv("OCTSEG_NO_SIDE_STREAM") && !serial_mode()) {
+  static const bool no_side = getenv("OCTSEG_NO_SIDE_STREAM") != nullptr;   // A/B switch
+  if (!no_side && !serial_mode()) {
     if (!P->side) {
       HIPCHK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));

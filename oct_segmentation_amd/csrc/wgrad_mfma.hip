@@ -163,10 +163,8 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
         for (int t = 0; t < NTAPS; ++t) {
           Tr<T>::mma(cur.y, cur.x[t], acc[t]);
           __builtin_amdgcn_sched_barrier(0);
-#ifndef OCTSEG_EXP_NOFRAG   // timing experiment: MFMAs on stale fragments
           if (t == 0) load_y1(kn, nxt);
           load_x1(xrow, t, nxt);
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       };
