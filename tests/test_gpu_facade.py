@@ -150,3 +150,30 @@ def test_graph_replay_matches_eager_forward(cuda):
     net.use_graph = True
     for _ in range(3):
         assert torch.equal(net(frames[1], normalize=False), e3)
+
+
+@pytest.mark.gpu
+def test_stream_schedule_does_not_change_results(cuda):
+    """Forward lanes + weight-gradient side stream (default) against every launch on one stream
+    (octseg_debug_set_serial): same logits and loss bit for bit, same gradients up to the split-K atomics' order."""
+    import torch
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.engine import SegNet
+    net = SegNet('unetplusplus', 'resnet34', classes=2, device=cuda, compute_dtype=torch.float32, seed=9).train()
+    img, mask = make_batch(2, 2, 128, seed=4)
+    img, mask = img.to(cuda), mask.to(cuda)
+    buf0 = net.bn_buffers.clone()
+    res = []
+    for serial in (0, 1):
+        net.bn_buffers.copy_(buf0)
+        L.check(L.lib().octseg_debug_set_serial(serial))
+        try:
+            loss, logits, stats = net.train_step_raw(img, mask)
+            torch.cuda.synchronize()
+        finally:
+            L.check(L.lib().octseg_debug_set_serial(0))
+        res.append((loss.clone(), logits.clone(), stats.clone(), net._grad_arena.clone(), net.bn_buffers.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+    scale = b[3].abs().max().item()
+    assert (a[3] - b[3]).abs().max().item() <= 1e-5 * max(scale, 1e-12)
