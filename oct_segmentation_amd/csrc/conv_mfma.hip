@@ -373,10 +373,16 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 
 // 4-wave variants must leave room for a second workgroup per CU (<= 256 registers): they serve the short layers
 // whose prologue / epilogue only hides under another workgroup's MFMAs
-template <typename T, int NT, int WN, int WM, int RB>
+// LOOP selects the main loop that is compiled into the instantiation (one kernel per loop: with all of them in one
+// function hipcc gives up on the by-value argument struct and moves it to scratch, and every layer pays the register
+// budget of the largest loop):  0 rolled tap loop (any tap table)   1 resident taps (one K chunk, small slabs)
+//                               2 1x1 (one tap, four window passes per chunk)   3 run9r (3x3, slab ring)
+enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3 };
+
+template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
   const int dbuf = mode & 1;
-  const bool resident = (mode & 2) != 0;   // single K chunk + small slabs: every tap's weights stay in LDS, no per-tap DMA / barrier
+  constexpr bool resident = LOOP == LOOP_RESIDENT;   // single K chunk + small slabs: every tap's weights stay in LDS, no per-tap DMA / barrier
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int BN = NT * 32 * WN;
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
     } else {
       dmaB(a.tap_w[0] * nchunks, 0);
-      if (mode & 16) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring (run9r): two slabs ahead
+      if constexpr (LOOP == LOOP_RUN9) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring (run9r): two slabs ahead
     }
     stage_full(cur, ldsA);
   }
@@ -732,16 +738,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail slabs
     __syncthreads();
   };
-  if (resident) {
+  if constexpr (LOOP == LOOP_RESIDENT) {
     for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
     __syncthreads();   // the epilogue reuses the LDS
-  } else if (dbuf && ntaps == 9 && npass <= 8 && (mode & 16) && !(mode & 8) && NDMA % NWAVES == 0) {
-    run9r();
-  } else if (dbuf) {
-    if (single) run(std::integral_constant<int, 4>{}, std::true_type{});
-    else run(std::integral_constant<int, 1>{}, std::true_type{});
+  } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
+    if constexpr (NDMA % NWAVES == 0 && RB == 128) run9r();
+  } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap
+    run(std::integral_constant<int, 4>{}, std::true_type{});
   } else {
-    run(std::integral_constant<int, 1>{}, std::false_type{});
+    if (dbuf) run(std::integral_constant<int, 1>{}, std::true_type{});
+    else run(std::integral_constant<int, 1>{}, std::false_type{});
   }
 
 #ifdef OCTSEG_STAMP
@@ -1155,20 +1161,32 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
   return main_loop > epi ? main_loop : epi;
 }
 
-template <typename T, int NT, int WN, int WM, int RB>
-hipError_t launch_variant(const ConvArgs& a, int dbuf, size_t lds, hipStream_t st) {
+template <typename T, int NT, int WN, int WM, int RB, int LOOP>
+hipError_t launch_loop(const ConvArgs& a, int mode, size_t lds, hipStream_t st) {
   constexpr int BN = NT * 32 * WN, TH = 4 * WM;
   const int mtiles = a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
   dim3 grid(mtiles, (a.Cout + BN - 1) / BN);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<T, NT, WN, WM, RB>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<T, NT, WN, WM, RB, LOOP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<T, NT, WN, WM, RB>), grid, dim3(64 * WM * WN), lds, st, a, dbuf);
+  hipLaunchKernelGGL((conv_mfma_kernel<T, NT, WN, WM, RB, LOOP>), grid, dim3(64 * WM * WN), lds, st, a, mode);
   return hipGetLastError();
+}
+
+template <typename T, int NT, int WN, int WM, int RB>
+hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hipStream_t st) {
+  switch (loop) {
+    case LOOP_RESIDENT: return launch_loop<T, NT, WN, WM, RB, LOOP_RESIDENT>(a, mode, lds, st);
+    case LOOP_1X1: return launch_loop<T, NT, WN, WM, RB, LOOP_1X1>(a, mode, lds, st);
+    case LOOP_RUN9:
+      if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9>(a, mode, lds, st);
+      else return hipErrorInvalidValue;
+    default: return launch_loop<T, NT, WN, WM, RB, LOOP_GENERIC>(a, mode, lds, st);
+  }
 }
 
 template <typename T, int NT, int WN, int WM>
@@ -1272,7 +1290,7 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
         {
           const size_t slab = (size_t)v.NT * 32 * v.WN * v.RB;
           const int nd = (int)(slab / 1024), nw = v.WM * v.WN;
-          static const bool no_ring3 = getenv("OCTSEG_NO_RING3") != nullptr;
+          static const bool no_ring3 = getenv("OCTSEG_NO_RING3") != nullptr || getenv("OCTSEG_NO_RUN9") != nullptr;   // A/B switches
           if (!no_ring3 && pref_dbuf && a.ntaps == 9 && npass <= 8 && nd % nw == 0 && lds + slab <= cap) { c.ring3 = 1; c.lds = lds + slab; }
         }
         // thin layers: one K chunk and slabs small enough to keep all taps in LDS -> no per-tap DMA wait / barrier
@@ -1305,10 +1323,10 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
 #undef OCTSEG_PIPE
     return hipErrorInvalidValue;
   }
-  static const bool no_run9 = getenv("OCTSEG_NO_RUN9") != nullptr;   // A/B switch: the rolled tap loop instead of run9r
+  const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (c.resident << 1) | (no_run9 ? 8 : 0) | (c.ring3 ? 16 : 0), c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, loop, c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)
