@@ -637,6 +637,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       }
     }
   };
+  // 1x1 convs (one tap, four window passes per K chunk): the rolled loop loads a chunk's window at the top of an
+  // iteration and stores it at the bottom of the same one.  Here the loads of chunk c + 2 are issued in iteration c
+  // and stored in iteration c + 1 -- a whole iteration of MFMAs later -- with two named register sets and two
+  // stagers (the lazy-BN parameters follow the chunk), written out for a pair of iterations so that no register
+  // copy is needed.  All loads are plain C++ (hipcc counts them itself); the slab DMA is issued first in an
+  // iteration, so the explicit `vmcnt(PPT)` in front of the barrier retires it and leaves only the young window
+  // loads in flight.
+  auto run1p = [&]() __attribute__((always_inline)) {
+    constexpr int PPT = 4;
+    Stager sA, sB;
+    uint4 avA[PPT], avB[PPT];
+    bool okA[PPT], okB[PPT];
+    auto load_chunk = [&](Stager& sg, int chunk, uint4 (&av)[PPT], bool (&ok)[PPT]) __attribute__((always_inline)) {
+      sg.setup(a.src, a.nsrc, a.Cin, min(chunk, nchunks - 1), tid);
+      sg.bind_image(n);
+      int hy = hy_first, hx = hx_first, hp = p0w;
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        av[u] = sg.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok[u]);
+        const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+        if (adv) {
+          hp += Stager::PSTEP;
+          hy += dq; hx += dr;
+          if (hx >= RW) { hx -= RW; hy += 1; }
+        }
+      }
+    };
+    auto store_chunk = [&](const Stager& sg, char* win, const uint4 (&av)[PPT], const bool (&ok)[PPT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) sg.write_at(win + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, av[u], ok[u]);
+    };
+    auto body = [&](int c, Stager& sld, uint4 (&avl)[PPT], bool (&okl)[PPT], const Stager& sst, const uint4 (&avs)[PPT],
+                    const bool (&oks)[PPT]) __attribute__((always_inline)) {
+      dmaB(a.tap_w[0] * nchunks + min(c + 1, nchunks - 1), (c + 1) & 1);   // slab of the next iteration: oldest in the queue
+      load_chunk(sld, c + 2, avl, okl);
+      mma_tap(ldsA + ((c & 1) ? abytes : 0), ldsB + (c & 1) * BBYTES, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(sst, ldsA + ((c & 1) ? 0 : abytes), avs, oks);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPT) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    load_chunk(sB, 1, avB, okB);
+    for (int c = 0; c < nchunks; c += 2) {
+      body(c, sA, avA, okA, sB, avB, okB);
+      if (c + 1 < nchunks) body(c + 1, sB, avB, okB, sA, avA, okA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   // 3x3 taps, double-buffered window, THREE-slot slab ring (host: only when LDS allows): the chunk body is written
   // out tap by tap.  The window slice loaded in tap t is stored to LDS at the end of tap t + 1 -- a whole tap of
   // MFMAs later (stamps: waiting for it in the same tap cost ~800 of a tap's ~2900 cycles) -- and the slabs are
@@ -743,8 +793,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     __syncthreads();   // the epilogue reuses the LDS
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
     if constexpr (NDMA % NWAVES == 0 && RB == 128) run9r();
-  } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap
-    run(std::integral_constant<int, 4>{}, std::true_type{});
+  } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
+    if (mode & 8) run(std::integral_constant<int, 4>{}, std::true_type{});   // A/B switch OCTSEG_NO_RUN1P
+    else run1p();
   } else {
     if (dbuf) run(std::integral_constant<int, 1>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::false_type{});
@@ -1323,10 +1374,11 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
 #undef OCTSEG_PIPE
     return hipErrorInvalidValue;
   }
+  static const bool no_run1p = getenv("OCTSEG_NO_RUN1P") != nullptr;   // A/B switch
   const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, loop, c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (no_run1p ? 8 : 0), loop, c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)
