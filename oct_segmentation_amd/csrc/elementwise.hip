@@ -190,18 +190,29 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
   constexpr int VEC = EV<T>::VEC;
   const size_t nvec = a.npix * (size_t)(a.C / VEC);
   const int vpc = a.C / VEC;
-  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(v % vpc) * VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t v0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the grid stride is a multiple of the vectors per pixel (launch_bn_act): a thread keeps its channel vector for the
+  // whole sweep, so the per-channel parameters are loaded once (the 64-bit modulo and 2-4 scalar loads per channel
+  // per vector made this kernel instruction bound at half the HBM rate)
+  const int c = (int)(v0 % vpc) * VEC;
+  float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = a.scale[c + i]; sh[i] = a.shift[c + i];
+    rsc[i] = a.rscale ? a.rscale[c + i] : 1.f; rsh[i] = a.rscale ? a.rshift[c + i] : 0.f;
+  }
+  for (size_t v = v0; v < nvec; v += stride) {
     float x[VEC];
     EV<T>::unpack(ldv<T>(a.y, v), x);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) x[i] = fmaf(x[i], a.scale[c + i], a.shift[c + i]);
+    for (int i = 0; i < VEC; ++i) x[i] = fmaf(x[i], sc[i], sh[i]);
     if (a.res) {
       float rr[VEC];
       EV<T>::unpack(ldv<T>(a.res, v), rr);
       if (a.rscale) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) rr[i] = fmaf(rr[i], a.rscale[c + i], a.rshift[c + i]);
+        for (int i = 0; i < VEC; ++i) rr[i] = fmaf(rr[i], rsc[i], rsh[i]);
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) x[i] += rr[i];
@@ -219,9 +230,19 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
     stv<T>(a.out, v, EV<T>::pack(x));
   }
 }
+// grid for the per-channel elementwise kernels: the stride (grid * 256 threads) must be a multiple of vpc
+static inline int grid_for_channels(size_t nvec, int vpc) {
+  int g = grid_for(nvec, 256);
+  int a = vpc, b = 256;
+  while (b) { const int t = a % b; a = b; b = t; }   // a = gcd(vpc, 256)
+  const int m = vpc / a;                              // the grid must be a multiple of m
+  g = (g / m) * m;
+  return g < m ? m : g;
+}
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
-  const size_t nvec = a.npix * (size_t)(a.C / (dtype == DT_F32 ? 4 : 8));
-  const int g = grid_for(nvec, 256);
+  const int vpc = a.C / (dtype == DT_F32 ? 4 : 8);
+  const size_t nvec = a.npix * (size_t)vpc;
+  const int g = grid_for_channels(nvec, vpc);
   if (dtype == DT_F32) hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
   return hipGetLastError();
@@ -304,8 +325,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = a.C / VEC;
   const size_t nvec = a.npix * (size_t)vpc;
-  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(v % vpc) * VEC;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t v0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(v0 % vpc) * VEC;   // loop invariant: the stride is a multiple of vpc (launch_bn_bwd_apply)
+  // dy = A * dz - (A * c1 - A * c2 * mean * rstd) - (A * c2 * rstd) * y,  A = gamma * rstd: three FMAs per element
+  float sc[VEC], sh[VEC], mu[VEC], rs[VEC], A[VEC], c1[VEC], c2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = a.scale[c + i]; sh[i] = a.shift[c + i]; mu[i] = a.mean[c + i]; rs[i] = a.rstd[c + i];
+    A[i] = a.gamma[c + i] * rs[i]; c1[i] = a.coef[2 * (c + i)]; c2[i] = a.coef[2 * (c + i) + 1];
+  }
+  for (size_t v = v0; v < nvec; v += stride) {
     float g[VEC], y[VEC];
     EV<T>::unpack(ldv<T>(a.g, v), g);
     EV<T>::unpack(ldv<T>(a.y, v), y);
@@ -316,19 +346,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
     } else if (a.mask == 1) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], a.scale[c + i], a.shift[c + i]) > 0.f)) g[i] = 0.f;
+      for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], sc[i], sh[i]) > 0.f)) g[i] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float xh = (y[i] - a.mean[c + i]) * a.rstd[c + i];
-      g[i] = a.gamma[c + i] * a.rstd[c + i] * (g[i] - a.coef[2 * (c + i)] - xh * a.coef[2 * (c + i) + 1]);
+      const float xh = (y[i] - mu[i]) * rs[i];
+      g[i] = A[i] * (g[i] - c1[i] - xh * c2[i]);
     }
     stv<T>(a.dy, v, EV<T>::pack(g));
   }
 }
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
-  const size_t nvec = a.npix * (size_t)(a.C / (dtype == DT_F32 ? 4 : 8));
-  const int g = grid_for(nvec, 256);
+  const int vpc = a.C / (dtype == DT_F32 ? 4 : 8);
+  const size_t nvec = a.npix * (size_t)vpc;
+  const int g = grid_for_channels(nvec, vpc);
   if (dtype == DT_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
   return hipGetLastError();
