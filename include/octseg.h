@@ -117,6 +117,14 @@ int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, v
                        const float* image, float* logits, int normalize, const float* mean,
                        const float* stdv, int train, void* stream);
 
+/* Serving epilogue (reference src/predict.py:92-100): out[n][y][x][out_ch] = sigmoid(logits[n][ch]) > 0.5 after a nearest
+ * resize from H x W to out_h x out_w.  logits: NCHW f32 [N,classes,H,W]; out: NHWC f32 [N,out_h,out_w,out_channels] (the
+ * reference's 4-channel mask stack, channel = CLASS_ID - 1).  row_index[out_h] / col_index[out_w]: device int32 source
+ * index of every output row / column -- the host mirror fills them with Pillow's NEAREST rule (steps accumulated in
+ * double, PIL.Image.resize), so the masks equal the reference's bit for bit; null = floor((i + 0.5) * H / out_h). */
+int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,
+                         int out_channels, int out_ch, const int* row_index, const int* col_index, void* stream);
+
 /* loss: device f32 scalar; stats: device int64 [B][classes][4] = tp, fp, fn, tn (nullable). */
 int octseg_dice_forward(octseg_plan* plan, void* workspace, const float* logits, const float* target,
                         float* loss, long long* stats, void* stream);

@@ -803,6 +803,31 @@ hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJ
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ serving: threshold + nearest resize + mask assembly
+// out[n][y][x][out_ch] = logits[n][ch][rows[y]][cols[x]] > 0  (sigmoid(z) > 0.5).  rows / cols: source index of every
+// output row / column (the caller builds them with the resize rule it wants bit-for-bit, e.g. Pillow's accumulated
+// double steps); null tables = floor((i + 0.5) * S / O) in exact integers.
+__global__ __launch_bounds__(256) void mask_assemble_kernel(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH,
+                                                            int OW, int OC, int out_ch, const int* rows, const int* cols) {
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % OW);
+    const int y = (int)((i / OW) % OH);
+    const int n = (int)(i / ((size_t)OW * OH));
+    int sy = rows ? rows[y] : (int)(((long long)(2 * y + 1) * SH) / (2 * OH));
+    int sx = cols ? cols[x] : (int)(((long long)(2 * x + 1) * SW) / (2 * OW));
+    sy = min(max(sy, 0), SH - 1); sx = min(max(sx, 0), SW - 1);
+    const float z = logits[(((size_t)n * C + ch) * SH + sy) * SW + sx];
+    out[i * OC + out_ch] = z > 0.f ? 1.f : 0.f;
+  }
+}
+hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,
+                                const int* rows, const int* cols, hipStream_t st) {
+  hipLaunchKernelGGL(mask_assemble_kernel, dim3(grid_for((size_t)N * OH * OW, 256)), dim3(256), 0, st, logits, N, C, SH, SW, ch, out, OH, OW,
+                     OC, out_ch, rows, cols);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ fused optimizers (torch defaults)
 __global__ __launch_bounds__(256) void optim_kernel(const OptArgs a, float bc1, float bc2, float radam_rect, int radam_use) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {

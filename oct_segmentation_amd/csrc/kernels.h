@@ -104,6 +104,10 @@ struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, t
 hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
                            unsigned long long total, hipStream_t st);
 
+// serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel
+hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,
+                                const int* rows, const int* cols, hipStream_t st);
+
 // fused optimizers over the flat fp32 arenas
 struct OptArgs {
   float* p; const float* g; float* m; float* v; size_t n;

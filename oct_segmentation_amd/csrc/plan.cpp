@@ -1120,6 +1120,19 @@ int octseg_plan_set_graph(octseg_plan* p, int enable) {
   return OCTSEG_OK;
 }
 
+// Serving epilogue of predict.py:92-100: sigmoid(logits[:, ch]) > 0.5, nearest resize (PIL semantics) to out_h x out_w,
+// written to channel out_ch of the NHWC mask stack out[N][out_h][out_w][out_channels] (f32 0/1).
+int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,
+                         int out_channels, int out_ch, const int* row_index, const int* col_index, void* stream) {
+  if (!logits || !out) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (N <= 0 || classes <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || ch < 0 || ch >= classes || out_ch < 0 ||
+      out_ch >= out_channels)
+    return fail(OCTSEG_BAD_SHAPE, "mask_assemble: channel / extent out of range");
+  HIPCHK(launch_mask_assemble(logits, N, classes, H, W, ch, out, out_h, out_w, out_channels, out_ch, row_index, col_index,
+                              (hipStream_t)stream));
+  return OCTSEG_OK;
+}
+
 int octseg_dice_forward(octseg_plan* p, void* workspace, const float* logits, const float* target, float* loss,
                         long long* stats, void* stream) {
   if (!p || !workspace || !logits || !target || !loss) return fail(OCTSEG_BAD_ARG, "null argument");

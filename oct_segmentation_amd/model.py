@@ -137,6 +137,15 @@ class OCTSegmentationModel(nn.Module):
         masks = (y.sigmoid() > 0.5).float().cpu()
         return masks.permute(0, 2, 3, 1).numpy().round()
 
+    def predict_logits(self, images):
+        """The device half of ``predict``: NHWC numpy in, NCHW float32 logits on the GPU out (no host round trip)."""
+        x = torch.as_tensor(np.ascontiguousarray(images.transpose((0, 3, 1, 2))), dtype=torch.float32).to(self.model.device)
+        was_training = self.model.training
+        try:
+            return self.model(x, normalize=False)
+        finally:
+            self.model.train(was_training)
+
     @staticmethod
     def to_tensor_shape(x):
         return x.transpose([2, 0, 1]).astype('float32')

@@ -46,25 +46,55 @@ def preprocessing_img(img, input_size):
     return np.asarray(img)[:, :, ::-1].copy()
 
 
-def segment(images, masks, output_size, classes, models_dir, device='cuda', batch_size=8, compute_dtype=torch.bfloat16):
-    """predict.py:61-101.  images: list of PIL images; masks: list of zero arrays [H_out, W_out, 4]."""
-    cache = {}
+def pil_nearest_index(src, dst):
+    """Source index of every output pixel of ``PIL.Image.resize((dst, ...), NEAREST)``: Pillow steps a double by
+    src/dst from src/dst/2 and truncates, so exact-integer positions may fall on either side; same arithmetic here."""
+    a0 = src / dst
+    xx = a0 * 0.5
+    out = np.empty(dst, dtype=np.int32)
+    for i in range(dst):
+        out[i] = min(int(xx), src - 1)
+        xx += a0
+    return out
+
+
+def segment(images, masks, output_size, classes, models_dir, device='cuda', batch_size=8, compute_dtype=torch.bfloat16,
+            use_graph=False):
+    """predict.py:61-101.  images: list of PIL images; masks: list of zero arrays [H_out, W_out, 4].
+
+    Every model runs once (the reference runs FC_LC once per class), in batches; thresholding, the nearest resize to
+    ``output_size`` and the 4-channel mask assembly happen on the GPU (``octseg_mask_assemble``); one D2H copy of the
+    assembled 0/1 stack at the end instead of one logits tensor per frame and class."""
+    from . import _lib as L
+    n = len(images)
+    # PIL sizes are (width, height); the reference allocates masks as [output_size[0], output_size[1], 4] and resizes
+    # to tuple(output_size): it only ever uses square sizes, and so do the extents below
+    oh, ow = masks[0].shape[0], masks[0].shape[1]
+    stack = torch.zeros((n, oh, ow, 4), dtype=torch.float32, device=device)
+    cache, tables = {}, {}
     for class_name in classes:
         meta = MODELS_META[class_name]
         model_dir = os.path.join(models_dir, meta['model_dir'])
         if model_dir not in cache:
-            model, cfg = load_model(model_dir, device, compute_dtype)
+            model, cfg = load_model(model_dir, device, compute_dtype, use_graph=use_graph)
             batch = np.array([preprocessing_img(img, cfg['input_size']) for img in images])
-            preds = []
-            for i in range(0, len(batch), batch_size):
-                preds.append(model.predict(images=batch[i:i + batch_size], device=device))
-            cache[model_dir] = np.concatenate(preds, axis=0)
+            logits = [model.predict_logits(batch[i:i + batch_size]) for i in range(0, n, batch_size)]
+            cache[model_dir] = torch.cat(logits, dim=0)
             del model
-        preds = cache[model_dir]
-        for i, mask in enumerate(masks):
-            ch = preds[i][:, :, meta['index']] if preds[i].ndim > 2 else preds[i]
-            resized = np.asarray(Image.fromarray((ch * 255).astype(np.uint8)).resize(tuple(output_size), Image.NEAREST)) / 255.0
-            mask[:, :, CLASS_IDS[class_name] - 1] = resized
+        z = cache[model_dir]
+        ch = meta['index'] if z.shape[1] > 1 else 0
+        key = (z.shape[2], z.shape[3])
+        if key not in tables:   # PIL size = (width, height) = tuple(output_size): columns follow output_size[0]
+            tables[key] = (torch.from_numpy(pil_nearest_index(z.shape[2], oh)).to(device),
+                           torch.from_numpy(pil_nearest_index(z.shape[3], ow)).to(device))
+        rows, cols = tables[key]
+        L.check(L.lib().octseg_mask_assemble(L.ptr(z), n, z.shape[1], z.shape[2], z.shape[3], int(ch), L.ptr(stack), oh, ow, 4,
+                                             CLASS_IDS[class_name] - 1, L.ptr(rows), L.ptr(cols), L.stream_ptr()))
+    host = stack.cpu().numpy()
+    for i, mask in enumerate(masks):
+        for class_name in classes:
+            c = CLASS_IDS[class_name] - 1
+            mask[:, :, c] = host[i, :, :, c]
     return masks
 
 

@@ -119,6 +119,15 @@ def test_segment_ensemble_channel_mapping(cuda, tmp_path):
     lc = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
     fc = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
     assert np.array_equal(out[0][:, :, 2], lc) and np.array_equal(out[0][:, :, 1], fc)
+    # the GPU threshold + nearest resize (octseg_mask_assemble) follows PIL's index rule when shrinking and for odd ratios too
+    for osz in (48, 37, 100):
+        masks2 = [np.zeros((osz, osz, 4)) for _ in images]
+        out2 = segment(images, masks2, [osz, osz], ['Lipid core', 'Fibrous cap'], str(tmp_path), device='cuda',
+                       compute_dtype=torch.float32)
+        lc2 = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((osz, osz), Image.NEAREST)) / 255.0
+        fc2 = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((osz, osz), Image.NEAREST)) / 255.0
+        assert np.array_equal(out2[0][:, :, 2], lc2) and np.array_equal(out2[0][:, :, 1], fc2), osz
+        assert not out2[0][:, :, 0].any() and not out2[0][:, :, 3].any()   # classes that were not asked for stay empty
 
 
 @pytest.mark.gpu

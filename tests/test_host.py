@@ -112,3 +112,16 @@ def test_metrics_from_stats_match_oracle():
     ref = get_metrics(mask, pred, torch.tensor(0.25))
     for k in ref:
         assert ours[k] == pytest.approx(ref[k], rel=1e-6, abs=1e-9), k
+
+
+def test_pil_nearest_index_table_is_pillows_rule():
+    """The index tables handed to octseg_mask_assemble reproduce PIL.Image.resize(..., NEAREST) exactly, including the
+    positions that fall on an integer (Pillow accumulates the step in double and truncates)."""
+    import numpy as np
+    from PIL import Image
+    from oct_segmentation_amd.predict import pil_nearest_index
+    for src in (64, 224, 512, 704, 100, 37):
+        img = Image.fromarray(np.tile(np.arange(src, dtype=np.float32), (2, 1)))
+        for dst in (96, 48, 37, 100, 704, 512, 300, 33, 63, 65, 1000):
+            want = np.asarray(img.resize((dst, 2), Image.NEAREST))[0].astype(np.int64)
+            assert np.array_equal(pil_nearest_index(src, dst), want), (src, dst)
