@@ -24,7 +24,38 @@ CASES = {
     'unetplusplus_resnet18': ('unetplusplus', 'resnet18', 2, 2, 64, 102),
     'linknet_resnet18': ('linknet', 'resnet18', 2, 2, 64, 103),
     'unet_resnet50': ('unet', 'resnet50', 1, 2, 64, 108),
+    # SURVEY.md section 8c list: bottleneck-encoder variants of the other two decoders, a non-square frame, and
+    # BASELINE config c1 (U-Net / resnet18, 256 x 256, B = 2) itself
+    'unetplusplus_resnet50': ('unetplusplus', 'resnet50', 1, 2, 64, 110),
+    'linknet_resnet50': ('linknet', 'resnet50', 2, 2, 64, 111),
+    'unet_resnet18_96x64': ('unet', 'resnet18', 2, 2, (96, 64), 112),
+    'c1_unet_resnet18_256': ('unet', 'resnet18', 1, 2, 256, 116),
 }
+# cases larger than this many logits store a centre crop + checksums instead of the full tensor
+FULL_LOGITS_MAX = 64 * 1024
+
+
+def case_batch(B, classes, S, seed):
+    """Synthetic batch of a case; a (H, W) size is cut out of the square frame of side max(H, W)."""
+    from synth import make_batch
+    if isinstance(S, tuple):
+        H, W = S
+        img, mask = make_batch(B, classes, max(H, W), seed=seed, empty_last=(classes > 1))
+        return img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
+    return make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+
+
+def summarize_logits(z):
+    """What is stored of a logits array [B, C, H, W]: all of it, or (large cases) a 32 x 32 centre crop of every
+    channel plus float64 sum, sum of squares and sum of |z|."""
+    z = np.asarray(z, dtype=np.float32)
+    if z.size <= FULL_LOGITS_MAX:
+        return {'logits': z}
+    H, W = z.shape[2], z.shape[3]
+    crop = z[:, :, H // 2 - 16:H // 2 + 16, W // 2 - 16:W // 2 + 16].copy()
+    z64 = z.astype(np.float64)
+    return {'logits_crop': crop, 'logits_sums': np.array([z64.sum(), (z64 * z64).sum(), np.abs(z64).sum()]),
+            'logits_absmax': np.float64(np.abs(z64).max())}
 
 
 def build(arch, enc, classes, seed, kinkfree=True):
@@ -44,9 +75,8 @@ def build(arch, enc, classes, seed, kinkfree=True):
 
 def run_case(arch, enc, classes, B, S, seed):
     from oracle import DiceLoss, get_stats
-    from synth import make_batch
     m = build(arch, enc, classes, seed)
-    img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+    img, mask = case_batch(B, classes, S, seed)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     logits = m((img - mean) / std)
@@ -61,6 +91,8 @@ def run_case(arch, enc, classes, B, S, seed):
 if __name__ == '__main__':
     for name, case in CASES.items():
         out = run_case(*case)
-        np.savez_compressed(os.path.join(HERE, f'{name}.npz'), logits=out['logits'].astype(np.float32), loss=np.float64(out['loss']),
-                            grad_abs_sums=out['grad_abs_sums'], stats=out['stats'])
+        if os.path.exists(os.path.join(HERE, f'{name}.npz')) and '--all' not in sys.argv:
+            continue   # committed vectors are only regenerated on request
+        np.savez_compressed(os.path.join(HERE, f'{name}.npz'), loss=np.float64(out['loss']), grad_abs_sums=out['grad_abs_sums'],
+                            stats=out['stats'], **summarize_logits(out['logits']))
         print(name, 'loss', out['loss'], 'logits', out['logits'].shape)

@@ -12,23 +12,31 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-@pytest.mark.parametrize('name', ['unet_resnet18', 'unetplusplus_resnet18', 'linknet_resnet18', 'unet_resnet50'])
+@pytest.mark.parametrize('name', ['unet_resnet18', 'unetplusplus_resnet18', 'linknet_resnet18', 'unet_resnet50', 'unetplusplus_resnet50',
+                                  'linknet_resnet50', 'unet_resnet18_96x64', 'c1_unet_resnet18_256'])
 def test_engine_reproduces_golden_vectors(cuda, name):
-    from golden.make_golden import CASES, build
+    from golden.make_golden import CASES, build, case_batch, summarize_logits
     from oct_segmentation_amd.engine import SegNet
-    from synth import make_batch
     arch, enc, classes, B, S, seed = CASES[name]
     g = np.load(os.path.join(GOLDEN, f'{name}.npz'))
     ref = build(arch, enc, classes, seed)           # seeded weights only; no forward on the CPU here
     net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32)
     net.load_state_dict(ref.state_dict())
     net.train()
-    img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+    img, mask = case_batch(B, classes, S, seed)
     loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True,
                                              mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
     torch.cuda.synchronize()
-    scale = float(np.abs(g['logits']).max())
-    err = float(np.abs(logits.cpu().numpy() - g['logits']).max())
+    got = summarize_logits(logits.cpu().numpy())
+    if 'logits' in g:
+        scale = float(np.abs(g['logits']).max())
+        err = float(np.abs(got['logits'] - g['logits']).max())
+    else:   # large case: centre crop element-wise, the whole tensor through its float64 sums
+        scale = float(g['logits_absmax'])
+        err = float(np.abs(got['logits_crop'] - g['logits_crop']).max())
+        n = logits.numel()
+        assert abs(got['logits_sums'][0] - g['logits_sums'][0]) <= 2e-4 * max(1.0, scale) * n ** 0.5 * 4
+        assert abs(got['logits_sums'][2] - g['logits_sums'][2]) <= 2e-4 * max(1.0, scale) * n ** 0.5 * 4
     print(f'{name}: logits max|d| {err:.3e} (scale {scale:.2e}), loss {loss.item():.7f} vs {float(g["loss"]):.7f}')
     assert err <= 2e-4 * max(1.0, scale)
     assert abs(loss.item() - float(g['loss'])) <= 1e-5
