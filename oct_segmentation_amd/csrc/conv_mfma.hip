@@ -1321,7 +1321,9 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
   // (measured +6..23 % on the ResNet bottleneck shapes); the 8x16 tile costs them no halo worth mentioning
   {
     const int kc = (a.Cin <= (128 / esz) / 2 ? 64 : 128) / esz;
-    if (a.ntaps == 1 || a.Cin <= kc) wm_first = 2;
+    // (not for Cout <= 32: those workgroups are WM waves only, and two-wave workgroups measured 20-40 % slower
+    //  than four-wave ones on the thin full-resolution layers)
+    if ((a.ntaps == 1 || a.Cin <= kc) && WN > 1) wm_first = 2;
   }
   static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch
   if (force_wm) wm_first = force_wm;
