@@ -222,7 +222,7 @@ def main():
                         'profiles/r1_serial_kernel_stats.csv',
                 'overlapped': {
                     'note': 'the same brackets during the TIMED steps, where weight gradients and part of the decoder run on a '
-                            'side stream: durations include the time a kernel shares the chip (profiles/r1_r_bench_kernel_stats.csv)',
+                            'side stream: durations include the time a kernel shares the chip (profiles/r1_w_bench_kernel_stats.csv)',
                     'kernel_ms_per_step': round(sum(oms) / args.steps, 3),
                     'achieved': round(sum(ofl) / (sum(oms) * 1e-3) / 1e12, 2) if sum(oms) > 0 else 0.0,
                     'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
