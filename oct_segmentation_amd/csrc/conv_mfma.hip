@@ -377,7 +377,8 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 // function hipcc gives up on the by-value argument struct and moves it to scratch, and every layer pays the register
 // budget of the largest loop):  0 rolled tap loop (any tap table)   1 resident taps (one K chunk, small slabs)
 //                               2 1x1 (one tap, four window passes per chunk)   3 run9r (3x3, slab ring)
-enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3 };
+//                               4 run9s (3x3, ONE K chunk: slab ring only -- the K-thin data gradients of the decoder)
+enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4 };
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
     } else {
       dmaB(a.tap_w[0] * nchunks, 0);
-      if constexpr (LOOP == LOOP_RUN9) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring (run9r): two slabs ahead
+      if constexpr (LOOP == LOOP_RUN9 || LOOP == LOOP_RUN9S) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring: two slabs ahead
     }
     stage_full(cur, ldsA);
   }
@@ -791,6 +792,36 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   if constexpr (LOOP == LOOP_RESIDENT) {
     for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
     __syncthreads();   // the epilogue reuses the LDS
+  } else if constexpr (LOOP == LOOP_RUN9S) {   // host-checked: ONE K chunk, 9 taps, slab pieces divide over the waves
+    // single window, nothing to prefetch but the slabs: three-slot ring, the DMA of iteration t + 2 behind the
+    // MFMAs of k-step 0, one counted wait per tap (the rolled loop drains vmcnt(0) every tap: these are the K-thin,
+    // N-wide data gradients of the decoder's concat layers)
+    if constexpr (NDMA % NWAVES == 0 && RB == 128) {
+      int slotC = 0, slotS = 2;
+      auto tap = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int TT = decltype(tc)::value;
+        const int toff = __builtin_amdgcn_readlane(v_toff, TT);
+        const char* bsl = ldsB + slotC * BBYTES;
+        if (++slotC == 3) slotC = 0;
+        mma_tap_f(ldsA, bsl, toff,
+          [&]() {
+            if constexpr (TT + 2 < 9) dmaB(__builtin_amdgcn_readlane(v_tapw, TT + 2) * nchunks, slotS);
+            if (++slotS == 3) slotS = 0;
+          },
+          [&]() {   // the slab of the next tap (issued one tap ago) has landed; this tap's DMA may fly
+            if constexpr (TT + 2 < 9) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          },
+          [&]() {});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      };
+      tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+      tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+      tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    }
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
     if constexpr (NDMA % NWAVES == 0 && RB == 128) run9r();
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
@@ -1236,6 +1267,9 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
     case LOOP_RUN9:
       if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9>(a, mode, lds, st);
       else return hipErrorInvalidValue;
+    case LOOP_RUN9S:
+      if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9S>(a, mode, lds, st);
+      else return hipErrorInvalidValue;
     default: return launch_loop<T, NT, WN, WM, RB, LOOP_GENERIC>(a, mode, lds, st);
   }
 }
@@ -1258,7 +1292,7 @@ hipError_t launch_pipe(const ConvArgs& a, int D, size_t lds, hipStream_t st) {
 
 // Tile choice: N tile from Cout, K chunk from Cin, M tile (16x16 or 8x16 pixels) from tile utilisation
 // and LDS fit (double-buffered window preferred).
-struct Choice { Variant v; int dbuf; size_t lds; int resident; int pipe; int ring3; };   // pipe = ring depth D of conv_pipe_kernel (0: conv_mfma_kernel)
+struct Choice { Variant v; int dbuf; size_t lds; int resident; int pipe; int ring3; int ring1; };   // ring1: run9s (one chunk)   // pipe = ring depth D of conv_pipe_kernel (0: conv_mfma_kernel)
 
 // LDS of conv_pipe_kernel at ring depth D (0 if the pipeline does not fit this geometry)
 size_t pipe_lds(const ConvArgs& a, const Variant& v, int esz, int D) {
@@ -1305,7 +1339,7 @@ Choice choose(const ConvArgs& a, int esz) {
 
 static Choice choose_legacy(const ConvArgs& a, int esz) {
   Choice c;
-  c.pipe = 0; c.ring3 = 0;
+  c.pipe = 0; c.ring3 = 0; c.ring1 = 0;
   int NT, WN;
   if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
   const int kc128 = 128 / esz;
@@ -1352,6 +1386,14 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
           const size_t extra = (size_t)(a.ntaps - 2) * slab;
           if (lds + extra <= 64 * 1024) { c.resident = 1; c.lds = lds + extra; }
         }
+        // one K chunk, 3x3, slabs too big to stay resident: slab ring with counted waits (run9s)
+        {
+          const int nd = (int)(slab / 1024), nw = v.WM * v.WN;
+          static const bool no_run9s = getenv("OCTSEG_NO_RUN9S") != nullptr || getenv("OCTSEG_NO_RUN9") != nullptr;   // A/B switches
+          if (!no_run9s && !c.resident && !pref_dbuf && nchunks_c == 1 && a.ntaps == 9 && v.RB == 128 && nd % nw == 0 && lds + slab <= cap) {
+            c.ring1 = 1; c.lds = lds + slab;
+          }
+        }
         return c;
       }
     }
@@ -1377,7 +1419,7 @@ hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
     return hipErrorInvalidValue;
   }
   static const bool no_run1p = getenv("OCTSEG_NO_RUN1P") != nullptr;   // A/B switch
-  const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC));
+  const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
     return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (no_run1p ? 8 : 0), loop, c.lds, st);
