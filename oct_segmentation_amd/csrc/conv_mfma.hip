@@ -671,11 +671,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     };
     auto body = [&](int c, Stager& sld, uint4 (&avl)[PPT], bool (&okl)[PPT], const Stager& sst, const uint4 (&avs)[PPT],
                     const bool (&oks)[PPT]) __attribute__((always_inline)) {
-      dmaB(a.tap_w[0] * nchunks + min(c + 1, nchunks - 1), (c + 1) & 1);   // slab of the next iteration: oldest in the queue
-      load_chunk(sld, c + 2, avl, okl);
-      mma_tap(ldsA + ((c & 1) ? abytes : 0), ldsB + (c & 1) * BBYTES, 0);
+      char* wnext = ldsA + ((c & 1) ? 0 : abytes);
+      mma_tap_f(ldsA + ((c & 1) ? abytes : 0), ldsB + (c & 1) * BBYTES, 0,
+        [&]() {   // behind k-step 0: slab of the next iteration (oldest in the queue), then the loads of chunk c + 2
+          dmaB(a.tap_w[0] * nchunks + min(c + 1, nchunks - 1), (c + 1) & 1);
+          load_chunk(sld, c + 2, avl, okl);
+        },
+        [&]() {   // behind k-steps 1 and 2: lazy BN + LDS stores of chunk c + 1 (loaded one iteration ago)
+#pragma unroll
+          for (int u = 0; u < PPT / 2; ++u) sst.write_at(wnext + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, avs[u], oks[u]);
+        },
+        [&]() {
+#pragma unroll
+          for (int u = PPT / 2; u < PPT; ++u) sst.write_at(wnext + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, avs[u], oks[u]);
+        });
       __builtin_amdgcn_sched_barrier(0);
-      store_chunk(sst, ldsA + ((c & 1) ? 0 : abytes), avs, oks);
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPT) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
