@@ -222,3 +222,37 @@ def test_fused_optimizer_matches_torch(cuda, opt):
     err = (p.cpu() - p_ref.detach()).abs().max().item()
     print(opt, err)
     assert err < 1e-5
+
+
+@pytest.mark.parametrize('arch,enc,S,B', [('unetplusplus', 'resnet34', 256, 2), ('unet', 'resnet50', 224, 3), ('linknet', 'resnet34', 320, 2)])
+def test_parity_at_larger_frames_fp32(cuda, arch, enc, S, B):
+    """The same train-step parity on frames large enough for multi-chunk 16x16 tiles, ragged borders (224 = 14 x 16,
+    320 / 32 = 10) and every main loop of the conv kernel; kink-free BN biases so that gradients are comparable."""
+    from oracle import create_model, DiceLoss
+    from oracle.nets import randomize_bn
+    from oct_segmentation_amd.engine import SegNet
+    torch.manual_seed(7)
+    ref = create_model(arch, enc, classes=2)
+    randomize_bn(ref, 7)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.bias.copy_(8.0 * ((torch.rand(m.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+    ref.train()
+    net = SegNet(arch, enc, classes=2, device=cuda, compute_dtype=torch.float32)
+    net.load_state_dict(ref.state_dict())
+    net.train()
+    img, mask = make_batch(B, 2, S, seed=5)
+    z = ref(img)
+    loss_ref = DiceLoss()(z, mask)
+    loss_ref.backward()
+    loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    scale = z.detach().abs().max().item()
+    err = (logits.cpu() - z.detach()).abs().max().item()
+    cos, worst, name = _grad_report(net.named_grads(), ref)
+    print(f'{arch}/{enc} {S}x{S}: logits max|d| {err:.2e} (scale {scale:.1f}), grad cosine {cos:.9f}, worst {worst:.2e} ({name})')
+    assert err <= 2e-4 * max(1.0, scale)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert cos >= 0.999999 and worst < 2e-3
