@@ -470,7 +470,7 @@ hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride
 // ------------------------------------------------------------------ maxpool 3x3 s2 p1
 // Ties resolve to the first maximum in (row, column) scan order, as torch's CPU kernel does.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* out, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* out, unsigned char* idx, int N, int H, int W, int C) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC, OH = H / 2, OW = W / 2;
   const size_t nvec = (size_t)N * OH * OW * vpc;
@@ -481,8 +481,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* 
     const int oy = (int)(p % OH);
     const int n = (int)(p / OH);
     float m[VEC];
+    unsigned char am[VEC];   // window position (r * 3 + s) of the first maximum: the backward reads it back
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+    for (int i = 0; i < VEC; ++i) { m[i] = -INFINITY; am[i] = 255; }
     for (int r = 0; r < 3; ++r) {
       const int iy = 2 * oy - 1 + r;
       if (iy < 0 || iy >= H) continue;
@@ -492,24 +493,30 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* 
         float x[VEC];
         EV<T>::unpack(ldv<T>(in, (((size_t)n * H + iy) * W + ix) * vpc + cv), x);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) if (x[i] > m[i] || x[i] != x[i]) m[i] = x[i];
+        for (int i = 0; i < VEC; ++i) if (x[i] > m[i] || x[i] != x[i]) { m[i] = x[i]; am[i] = (unsigned char)(r * 3 + s); }
       }
     }
     stv<T>(out, v, EV<T>::pack(m));
+    if (idx != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) idx[v * VEC + i] = am[i];
+    }
   }
 }
-hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H, int W, int C, hipStream_t st) {
+hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t st) {
   const size_t nvec = (size_t)N * (H / 2) * (W / 2) * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, out, N, H, W, C);
-  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, out, N, H, W, C);
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
   return hipGetLastError();
 }
 
-// gather form: every input pixel re-derives, for each of the <=4 windows that cover it, whether it
-// is that window's first maximum; no atomics, deterministic.
+// backward from the saved window positions: an input pixel sits at position (iy - 2 oy + 1) * 3 + (ix - 2 ox + 1) of each of
+// the <= 4 windows that cover it and receives that window's gradient iff the forward recorded that position
+// (4 x (1 + 2) bytes per element instead of re-deriving four 9-element argmaxes)
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const void* gout, void* gin, int N, int H, int W, int C, int store) {
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned char* idx, const void* gout, void* gin, int N, int H, int W,
+                                                              int C, int store) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC, OH = H / 2, OW = W / 2;
   const size_t nvec = (size_t)N * H * W * vpc;
@@ -519,39 +526,29 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const 
     const int ix = (int)(p % W); p /= W;
     const int iy = (int)(p % H);
     const int n = (int)(p / H);
-    float acc[VEC], gi[VEC];
+    float gi[VEC];
     if (store) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) gi[i] = 0.f;
     } else {
       EV<T>::unpack(ldv<T>(gin, v), gi);
     }
+    float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
       if (oy >= OH) continue;
-      for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
         if (ox >= OW) continue;
-        // first maximum of window (oy, ox)
-        float m[VEC]; int arg[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) { m[i] = -INFINITY; arg[i] = -1; }
-        for (int r = 0; r < 3; ++r) {
-          const int yy = 2 * oy - 1 + r;
-          if (yy < 0 || yy >= H) continue;
-          for (int s = 0; s < 3; ++s) {
-            const int xx = 2 * ox - 1 + s;
-            if (xx < 0 || xx >= W) continue;
-            float x[VEC];
-            EV<T>::unpack(ldv<T>(in, (((size_t)n * H + yy) * W + xx) * vpc + cv), x);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) if (x[i] > m[i] || x[i] != x[i]) { m[i] = x[i]; arg[i] = yy * W + xx; }
-          }
-        }
+        const int code = (iy - 2 * oy + 1) * 3 + (ix - 2 * ox + 1);
+        const size_t ov = (((size_t)n * OH + oy) * OW + ox) * vpc + cv;
         float g[VEC];
-        EV<T>::unpack(ldv<T>(gout, (((size_t)n * OH + oy) * OW + ox) * vpc + cv), g);
+        EV<T>::unpack(ldv<T>(gout, ov), g);
+        unsigned char am[VEC];
+        if (VEC == 8) { const uint2 w = *(const uint2*)(idx + ov * 8); *(uint2*)am = w; }
+        else { const unsigned w = *(const unsigned*)(idx + ov * 4); *(unsigned*)am = w; }
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) if (arg[i] == iy * W + ix) acc[i] += g[i];
+        for (int i = 0; i < VEC; ++i) if (am[i] == code) acc[i] += g[i];
       }
     }
 #pragma unroll
@@ -559,11 +556,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* in, const 
     stv<T>(gin, v, EV<T>::pack(gi));
   }
 }
-hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W, int C, int store, hipStream_t st) {
+hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const void* gout, void* gin, int N, int H, int W, int C, int store,
+                                  hipStream_t st) {
   const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C, store);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, gout, gin, N, H, W, C, store);
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(gr), dim3(256), 0, st, idx, gout, gin, N, H, W, C, store);
+  else hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, idx, gout, gin, N, H, W, C, store);
   return hipGetLastError();
 }
 

@@ -72,11 +72,10 @@ hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride
                               hipStream_t st);
 
 // maxpool 3x3 s2 p1 (NHWC T)
-hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, int N, int H, int W, int C,
-                              hipStream_t st);
-hipError_t launch_maxpool_bwd(int dtype, const void* in, const void* gout, void* gin, int N, int H, int W,
-                              int C, int store, hipStream_t st);
-
+hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx /*nullable: window position of every maximum*/,
+                              int N, int H, int W, int C, hipStream_t st);
+hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const void* gout, void* gin, int N, int H, int W, int C, int store,
+                                  hipStream_t st);
 // stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the 7x7 s2 p3 conv
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
                               const float* mean, const float* stdv, int normalize, hipStream_t st);

@@ -548,6 +548,12 @@ static int build_plan(octseg_plan* P) {
   P->slab_off = off; P->slab_bytes = align_up(slab); off += 2 * align_up(slab);          // one slab per forward lane
   P->fin_part_off = off; off += 2 * align_up(4096 * 2 * sizeof(double));   // two-level slab reduction scratch (per lane)
   P->fin_cnt_off = off; off += align_up(2 * 64 * sizeof(unsigned));
+  {
+    size_t pool_elems = 0;
+    for (auto& op : P->ops)
+      if (op.kind == OP_MAXPOOL) { const TensorInfo& t = P->tensors[op.out]; pool_elems = std::max(pool_elems, (size_t)t.N * t.H * t.W * t.C); }
+    P->pool_idx_off = off; off += align_up(pool_elems);   // one buffer: the ResNet stems have exactly one max-pool
+  }
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)P->classes * 3 * sizeof(double));
@@ -755,7 +761,8 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       case OP_MAXPOOL: {
         const TensorInfo& t = P->tensors[op.in];
         rc = need(lane, tseq[op.in]); if (rc) return rc;
-        HIPCHK(launch_maxpool_fwd(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, st));
+        HIPCHK(launch_maxpool_fwd(P->dtype, E.act(op.in), E.act(op.out), E.train ? (unsigned char*)(E.ws + P->pool_idx_off) : nullptr, t.N,
+                                  t.H, t.W, t.C, st));
         tseq[op.out] = stamp;
         break;
       }
@@ -955,7 +962,8 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
       case OP_MAXPOOL: {
         const TensorInfo& t = P->tensors[op.in];
         const int acc = E.claim(op.in);
-        HIPCHK(launch_maxpool_bwd(P->dtype, E.act(op.in), E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
+        HIPCHK(launch_maxpool_bwd_idx(P->dtype, (const unsigned char*)(E.ws + P->pool_idx_off), E.grad(op.out), E.grad(op.in), t.N, t.H, t.W,
+                                      t.C, acc ? 0 : 1, E.st));
         break;
       }
     }
