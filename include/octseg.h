@@ -16,8 +16,15 @@
  *                                      (model.py:73-95, train.py:130-133)
  *   octseg_optim_step                  configure_optimizers -> SGD|RMSprop|RAdam|Adam.step()
  *                                      (model.py:150-181)
+ *   octseg_mask_assemble               the per-frame epilogue of segment(): threshold, PIL NEAREST resize to output_size,
+ *                                      write into mask[:, :, CLASS_ID - 1] (src/predict.py:92-100, data/utils.py:16-33)
+ *   octseg_plan_set_graph              (serving option, no reference counterpart) eval forwards of predict()
+ *                                      (model.py:183-200) replayed as one hipGraph
+ *   octseg_plan_params_changed         optimizer.step() / load_state_dict() side effect: weight images are stale
  *   octseg_conv2d_* / _convT_*         torch conv2d / conv_transpose2d primitives, exported so the
  *                                      parity tests can pin every kernel against torch CPU in isolation
+ *   octseg_profile_* / octseg_debug_*  measurement aids of bench.py and tools/ (HIP-event brackets per launch, one-stream
+ *                                      mode, s_memtime stamps in -DOCTSEG_STAMP builds); no reference counterpart
  *
  * Conventions: every function returns 0 on success or a negative octseg_status; the message of the
  * last failure on the calling thread is octseg_last_error().  Nothing throws across the ABI.  The
