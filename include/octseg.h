@@ -16,6 +16,7 @@
  *                                      (model.py:73-95, train.py:130-133)
  *   octseg_optim_step                  configure_optimizers -> SGD|RMSprop|RAdam|Adam.step()
  *                                      (model.py:150-181)
+ *   octseg_augment                     OCTDataset.get_img_augmentation applied in __getitem__ (dataset.py:119-123,160-207)
  *   octseg_mask_assemble               the per-frame epilogue of segment(): threshold, PIL NEAREST resize to output_size,
  *                                      write into mask[:, :, CLASS_ID - 1] (src/predict.py:92-100, data/utils.py:16-33)
  *   octseg_plan_set_graph              (serving option, no reference counterpart) eval forwards of predict()
@@ -123,6 +124,18 @@ int octseg_plan_set_graph(octseg_plan* plan, int enable);
 int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,
                        const float* image, float* logits, int normalize, const float* mean,
                        const float* stdv, int train, void* stream);
+
+/* Training augmentation on the GPU (reference src/models/smp/dataset.py:160-207: HorizontalFlip, ShiftScaleRotate, RandomCrop +
+ * PadIfNeeded, GaussNoise, Perspective, RandomBrightnessContrast, HueSaturationValue).  The host draws the per-frame
+ * decisions and parameters (oct_segmentation_amd/augment.py mirrors the reference's probabilities and ranges) and passes
+ * OCTSEG_AUG_NPARAM floats per frame: [0..8] inverse homography (output pixel -> source pixel), [9] contrast alpha,
+ * [10] brightness beta (x 255), [11] noise sigma, [12] seed bits, [13..15] hue / saturation / value shifts in OpenCV
+ * 8-bit units, [16] flags (bit 0: HSV shift on), [20..28] inverse homography output pixel -> frame after crop + pad,
+ * [29..32] crop window [x_lo, y_lo, x_hi, y_hi) in that frame (outside = padding = 0).  One bilinear gather of the image (constant-0 border), one nearest
+ * gather per mask channel, photometric ops on the pixel, result clipped and rounded to the uint8 grid. */
+#define OCTSEG_AUG_NPARAM 36
+int octseg_augment(const float* img, const float* mask, float* img_out, float* mask_out, const float* params, int B,
+                   int classes, int H, int W, void* stream);
 
 /* Serving epilogue (reference src/predict.py:92-100): out[n][y][x][out_ch] = sigmoid(logits[n][ch]) > 0.5 after a nearest
  * resize from H x W to out_h x out_w.  logits: NCHW f32 [N,classes,H,W]; out: NHWC f32 [N,out_h,out_w,out_channels] (the

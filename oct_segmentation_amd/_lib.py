@@ -52,6 +52,7 @@ SYMBOLS = {
     'octseg_profile_stop': (C.c_int, [C.POINTER(C.c_double)]),
     'octseg_plan_params_changed': (C.c_int, [_P]),
     'octseg_plan_set_graph': (C.c_int, [_P, C.c_int]),
+    'octseg_augment': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'octseg_mask_assemble': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'octseg_net_forward': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_int, _P]),

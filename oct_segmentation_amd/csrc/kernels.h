@@ -107,6 +107,11 @@ hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJ
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,
                                 const int* rows, const int* cols, hipStream_t st);
 
+// on-GPU training augmentation (augment.hip): AUG_NPARAM floats per frame, layout in the kernel's header comment
+constexpr int AUG_NPARAM = 36;
+hipError_t launch_augment(const float* img, const float* mask, float* img_out, float* mask_out, const float* params, int B, int C, int H,
+                          int W, hipStream_t st);
+
 // fused optimizers over the flat fp32 arenas
 struct OptArgs {
   float* p; const float* g; float* m; float* v; size_t n;

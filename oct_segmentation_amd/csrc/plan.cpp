@@ -1128,6 +1128,17 @@ int octseg_plan_set_graph(octseg_plan* p, int enable) {
   return OCTSEG_OK;
 }
 
+// Training-input augmentation on the GPU (dataset.py:160-207): see augment.hip.  img [B,3,H,W] f32 BGR 0..255, mask
+// [B,classes,H,W] f32 0/1, params device f32 [B][OCTSEG_AUG_NPARAM]; outputs must not alias the inputs.
+int octseg_augment(const float* img, const float* mask, float* img_out, float* mask_out, const float* params, int B, int classes, int H,
+                   int W, void* stream) {
+  if (!img || !mask || !img_out || !mask_out || !params) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (B <= 0 || classes <= 0 || H <= 0 || W <= 0) return fail(OCTSEG_BAD_SHAPE, "augment: empty batch or frame");
+  if (img == img_out || mask == mask_out) return fail(OCTSEG_BAD_ARG, "augment: outputs must not alias the inputs (gather)");
+  HIPCHK(launch_augment(img, mask, img_out, mask_out, params, B, classes, H, W, (hipStream_t)stream));
+  return OCTSEG_OK;
+}
+
 // Serving epilogue of predict.py:92-100: sigmoid(logits[:, ch]) > 0.5, nearest resize (PIL semantics) to out_h x out_w,
 // written to channel out_ch of the NHWC mask stack out[N][out_h][out_w][out_channels] (f32 0/1).
 int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,

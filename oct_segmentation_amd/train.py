@@ -5,8 +5,10 @@ reference's ``config.json`` + ``weights.ckpt`` pair.  Data parallel when launche
 import json
 import os
 
+import numpy as np
 import torch
 
+from . import augment as augment_mod
 from .metrics import aggregate_epoch
 from .model import OCTSegmentationModel
 from . import parallel
@@ -21,7 +23,7 @@ def write_model_config(cfg, model_dir):
                    'batch_size': cfg['batch_size'], 'optimizer': cfg['optimizer'], 'lr': cfg['lr']}, f, indent=2)
 
 
-def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None):
+def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, augment_seed=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dt = torch.float32 if str(cfg.get('compute_dtype', 'bf16')) in ('fp32', 'float32') else torch.bfloat16
     model = OCTSegmentationModel(cfg['architecture'], cfg['encoder'], f"{cfg['architecture']}_{cfg['encoder']}", 3,
@@ -32,10 +34,15 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None):
         parallel.broadcast_parameters(net)
     opt = model.configure_optimizers()
     history = []
+    aug_rng = None
     for epoch in range(1, int(cfg['epochs']) + 1):
         model.train()
         model.training_step_outputs.clear()
         for img, mask in train_batches:
+            if cfg.get('use_augmentation', False):   # train.yaml use_augmentation (dataset.py:119-123), on the GPU
+                if aug_rng is None:
+                    aug_rng = np.random.default_rng(augment_seed)
+                img, mask = augment_mod.augment(img, mask, augment_mod.sample_params(img.shape[0], img.shape[-1], aug_rng))
             if world > 1:
                 parallel.broadcast_buffers(net)
             loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,

@@ -122,7 +122,7 @@ def test_fit_loop_writes_reference_style_model_dir(cuda, tmp_path):
     from oct_segmentation_amd.predict import load_model
     from oct_segmentation_amd.train import fit
     cfg = load_config('train', ['architecture=unet', 'encoder=resnet18', 'epochs=2', 'input_size=64', 'batch_size=2', 'lr=0.001',
-                                'compute_dtype=fp32'])
+                                'compute_dtype=fp32', 'use_augmentation=false'])
     cfg['classes'] = ['Lumen']
     batches = [tuple(t.to(cuda) for t in make_batch(2, 1, 64, seed=s)) for s in (1, 2, 3)]
     model, hist = fit(cfg, batches, val_batches=batches[:1], device=cuda, model_dir=str(tmp_path))
@@ -135,3 +135,17 @@ def test_fit_loop_writes_reference_style_model_dir(cuda, tmp_path):
     assert torch.equal(m2.model.arena.data, model.model.arena.data)
     out = m2.predict(np.zeros((1, 64, 64, 3), np.float32), 'cuda')
     assert out.shape == (1, 64, 64, 1)
+
+
+def test_fit_loop_with_gpu_augmentation(cuda, tmp_path):
+    """train.yaml's use_augmentation=true (the reference default) routes every batch through octseg_augment."""
+    from oct_segmentation_amd.config import load_config
+    from oct_segmentation_amd.train import fit
+    cfg = load_config('train', ['architecture=linknet', 'encoder=resnet18', 'epochs=2', 'input_size=64', 'batch_size=4', 'lr=0.001'])
+    assert cfg['use_augmentation'] is True
+    cfg['classes'] = ['Lipid core', 'Fibrous cap']
+    batches = [tuple(t.to(cuda) for t in make_batch(4, 2, 64, seed=s)) for s in (1, 2)]
+    model, hist = fit(cfg, batches, device=cuda, augment_seed=3)
+    assert len(hist) == 2 and np.isfinite(float(hist[1]['train']['loss'])) and 0.0 <= float(hist[1]['train']['loss']) <= 1.0
+    from oct_segmentation_amd import augment as A
+    assert np.array_equal(A.sample_params(4, 64, np.random.default_rng(3)), A.sample_params(4, 64, np.random.default_rng(3)))
