@@ -665,10 +665,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
         }
       }
     };
-    auto store_chunk = [&](const Stager& sg, char* win, const uint4 (&av)[PPT], const bool (&ok)[PPT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int u = 0; u < PPT; ++u) sg.write_at(win + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, av[u], ok[u]);
-    };
     auto body = [&](int c, Stager& sld, uint4 (&avl)[PPT], bool (&okl)[PPT], const Stager& sst, const uint4 (&avs)[PPT],
                     const bool (&oks)[PPT]) __attribute__((always_inline)) {
       char* wnext = ldsA + ((c & 1) ? 0 : abytes);
