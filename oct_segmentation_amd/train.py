@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import augment as augment_mod
-from .metrics import aggregate_epoch
+from .metrics import aggregate_epoch, save_metrics_on_epoch
 from .model import OCTSegmentationModel
 from . import parallel
 
@@ -53,12 +53,18 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
             from .metrics import get_metrics_from_stats
             model.training_step_outputs.append(get_metrics_from_stats(stats, loss))
         row = {'epoch': epoch, 'train': aggregate_epoch(model.training_step_outputs)}
+        rank0 = int(os.environ.get('RANK', '0')) == 0
+        if model_dir is not None and rank0:   # model.py:97-106: metrics.csv rows of the train split
+            save_metrics_on_epoch(model.training_step_outputs, 'train', model_dir, cfg['classes'], epoch)
         if val_batches is not None:
             model.eval()
             model.validation_step_outputs.clear()
             for batch in val_batches:
                 model.validation_step(batch)
             row['test'] = aggregate_epoch(model.validation_step_outputs)   # the reference calls the split 'test'
+            if model_dir is not None and rank0:   # model.py:134-148: test rows + best metrics
+                _, model.validation_best_metrics = save_metrics_on_epoch(model.validation_step_outputs, 'test', model_dir, cfg['classes'],
+                                                                         epoch, model.validation_best_metrics)
         history.append(row)
     if model_dir is not None and int(os.environ.get('RANK', '0')) == 0:
         write_model_config(cfg, model_dir)

@@ -131,6 +131,9 @@ def test_fit_loop_writes_reference_style_model_dir(cuda, tmp_path):
     with open(os.path.join(tmp_path, 'config.json')) as f:
         j = json.load(f)
     assert set(j) == {'model_name', 'architecture', 'encoder', 'input_size', 'classes', 'batch_size', 'optimizer', 'lr'}
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(tmp_path, 'metrics.csv'))))   # train + test rows, per class + Mean, per epoch
+    assert len(rows) == 2 * 2 * 2 and {r['Split'] for r in rows} == {'train', 'test'} and rows[1]['Class'] == 'Mean'
     m2, cfg2 = load_model(str(tmp_path), 'cuda', torch.float32)
     assert torch.equal(m2.model.arena.data, model.model.arena.data)
     out = m2.predict(np.zeros((1, 64, 64, 3), np.float32), 'cuda')

@@ -125,3 +125,26 @@ def test_pil_nearest_index_table_is_pillows_rule():
         for dst in (96, 48, 37, 100, 704, 512, 300, 33, 63, 65, 1000):
             want = np.asarray(img.resize((dst, 2), Image.NEAREST))[0].astype(np.int64)
             assert np.array_equal(pil_nearest_index(src, dst), want), (src, dst)
+
+
+def test_metrics_csv_bookkeeping(tmp_path):
+    """metrics.csv schema, per-class + Mean rows, pairwise-mean aggregation and best-metric tracking (utils.py:39-158)."""
+    import csv
+    import numpy as np
+    from oct_segmentation_amd.metrics import save_metrics_on_epoch, CSV_FIELDS
+    classes = ['Lipid core', 'Fibrous cap']
+    def batch(loss, iou):
+        iou = np.asarray(iou, dtype=np.float64)
+        return {'loss': np.array(loss), 'iou': iou, 'dice': 2 * iou / (iou + 1), 'recall': iou, 'precision': iou, 'f1': iou}
+    b = [batch(1.0, [[0.2, 0.4], [0.4, 0.8]]), batch(0.0, [[0.8, 0.0], [0.8, 0.0]]), batch(0.5, [[0.0, 0.0], [0.0, 0.0]])]
+    best = {}
+    s1, best = save_metrics_on_epoch(b, 'test', str(tmp_path), classes, 1, best)
+    assert s1['test/loss'] == pytest.approx(((1.0 + 0.0) / 2 + 0.5) / 2)                 # later batches weigh more
+    assert s1['test/iou (Lipid core)'] == pytest.approx(((0.3 + 0.8) / 2 + 0.0) / 2)
+    assert s1['test/iou'] == pytest.approx((s1['test/iou (Lipid core)'] + s1['test/iou (Fibrous cap)']) / 2)
+    s2, best = save_metrics_on_epoch(b[:2], 'test', str(tmp_path), classes, 2, best)
+    assert best['iou'] == {'value': s2['test/iou'], 'epoch': 2} and s2['test/iou'] > s1['test/iou']
+    rows = list(csv.DictReader(open(tmp_path / 'metrics.csv')))
+    assert list(rows[0].keys()) == CSV_FIELDS and len(rows) == 6
+    assert [r['Class'] for r in rows[:3]] == ['Lipid core', 'Fibrous cap', 'Mean'] and rows[3]['Epoch'] == '2' and rows[0]['Split'] == 'test'
+    assert float(rows[2]['IoU']) == pytest.approx(s1['test/iou'])
