@@ -159,13 +159,13 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = (C.c_double * 9)()
+    prof = (C.c_double * 12)()
     L.check(L.lib().octseg_profile_stop(prof))
     loss_val = float(loss.item())
     # Roofline pass (untimed, after the measured steps): the same step with every launch on one stream, so that the
     # HIP-event bracket of a launch is the duration of that kernel alone.  In the timed steps the weight gradients and
     # part of the decoder run on a side stream; brackets taken there also contain the time a kernel shares the chip.
-    prof_alone = (C.c_double * 9)()
+    prof_alone = (C.c_double * 12)()
     n_alone = 2
     L.check(L.lib().octseg_debug_set_serial(1))
     step()
@@ -238,6 +238,15 @@ def main():
                 out['roofline']['traffic_unit'] = 'HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_traffic.json)'
             except Exception:
                 pass
+        # the HBM-bound part of the step (SURVEY.md section 8d asks for both roofs): BatchNorm sweeps, kernels alone
+        if prof_alone[9] > 0:
+            gbs = prof_alone[10] / (prof_alone[9] * 1e-3) / 1e9
+            out['roofline_hbm'] = {
+                'bound': 'hbm', 'kernel': 'bn_bwd_apply + bn_bwd_reduce + bn_act (NHWC sweeps, 16-byte vectors)',
+                'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                'kernel_ms_per_step': round(prof_alone[9] / n_alone, 3), 'launches_per_step': round(prof_alone[11] / n_alone, 1),
+                'algorithmic_gbytes_per_step': round(prof_alone[10] / n_alone / 1e9, 2),
+                'note': 'algorithmic bytes = every tensor these sweeps read or write, once; same untimed single-stream pass as roofline'}
         note(f'GPU: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; MFMA kernels {ach:.1f} TFLOP/s')
         if not args.no_cpu_baseline and world == 1:
             note('CPU baseline (oracle, 1 frame) ...')

@@ -101,10 +101,11 @@ double octseg_plan_fwd_macs(const octseg_plan* plan);      /* conv multiply-accu
 int octseg_plan_find_tensor(const octseg_plan* plan, const char* conv_name, size_t* act_off,
                             size_t* grad_off, int* dims);
 
-/* Measurement hooks (bench.py): between _start and _stop every MFMA conv launch is bracketed by HIP
- * events on its launch stream.  _stop synchronises the device and fills out[9]:
- * out[3k+0..2] = {milliseconds, algorithmic FLOPs, launches} for k = 0 conv forward, 1 conv
- * data-gradient, 2 weight gradient. */
+/* Measurement hooks (bench.py): between _start and _stop every MFMA conv launch and every BatchNorm sweep is bracketed
+ * by HIP events on its launch stream.  _stop synchronises the device and fills out[12]:
+ * out[3k+0..2] = {milliseconds, algorithmic work, launches} for k = 0 conv forward, 1 conv data-gradient, 2 weight
+ * gradient (work = FLOPs) and k = 3 the HBM-bound BatchNorm sweeps bn_act / bn_bwd_reduce / bn_bwd_apply (work = bytes
+ * every tensor they read or write once). */
 int octseg_profile_start(void);
 int octseg_profile_stop(double* out);
 

@@ -44,9 +44,11 @@ hipEvent_t prof_event() {
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
+static bool g_prof_hbm = false;   // set with octseg_debug_set_serial
 struct ProfScope {
   hipStream_t st; ProfRec r; bool on;
   ProfScope(int kind, double flops, hipStream_t s, const std::string& name = std::string()) : st(s), on(g_prof_on) {
+    if (kind == 3 && !g_prof_hbm) on = false;   // the BatchNorm sweeps are only bracketed in the one-stream measurement pass
     if (!on) return;
     r.kind = kind; r.flops = flops; r.name = name; r.a = prof_event(); r.b = prof_event();
     if (!r.a || !r.b) { on = false; return; }
@@ -754,7 +756,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         }
         if (op.post >= 0) a.post = E.act(op.post);
         a.out = E.act(op.out); a.npix = (size_t)t.N * t.H * t.W; a.C = t.C; a.relu = op.relu;
-        HIPCHK(launch_bn_act(P->dtype, a, st));
+        {
+          const double tb = (double)a.npix * a.C * dtype_size(P->dtype);
+          ProfScope ps(3, tb * (2 + (a.res ? 1 : 0) + (a.post ? 1 : 0)), st, "bn_act");
+          HIPCHK(launch_bn_act(P->dtype, a, st));
+        }
         tseq[op.out] = stamp;
         break;
       }
@@ -800,9 +806,16 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   a.coef = E.bn_coef(bn);
   a.dy = E.grad(b.y);
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
-  HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
+  const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
+  {
+    ProfScope ps(3, tbytes * (mask == 2 ? 3 : 2), E.st, b.name + ".bwd_reduce");
+    HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
+  }
   HIPCHK(launch_bn_bwd_finalize(a, E.st));
-  HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
+  {
+    ProfScope ps(3, tbytes * (mask == 2 ? 4 : 3), E.st, b.name + ".bwd_apply");
+    HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
+  }
   return OCTSEG_OK;
 }
 
@@ -1049,7 +1062,7 @@ int octseg_profile_stop(double* out) {
   g_prof_on = false;
   if (!out) return fail(OCTSEG_BAD_ARG, "null argument");
   HIPCHK(hipDeviceSynchronize());
-  for (int i = 0; i < 9; ++i) out[i] = 0.0;
+  for (int i = 0; i < 12; ++i) out[i] = 0.0;
   FILE* dump = nullptr;
   if (const char* path = getenv("OCTSEG_PROFILE_DUMP")) dump = fopen(path, "w");
   if (dump) fprintf(dump, "layer,class,ms,gflop,tflops\n");
@@ -1057,7 +1070,7 @@ int octseg_profile_stop(double* out) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
     out[3 * r.kind] += ms; out[3 * r.kind + 1] += r.flops; out[3 * r.kind + 2] += 1.0;
-    if (dump) fprintf(dump, "%s,%s,%.4f,%.3f,%.1f\n", r.name.c_str(), r.kind == 0 ? "fwd" : r.kind == 1 ? "dgrad" : "wgrad", ms,
+    if (dump) fprintf(dump, "%s,%s,%.4f,%.3f,%.1f\n", r.name.c_str(), r.kind == 0 ? "fwd" : r.kind == 1 ? "dgrad" : r.kind == 2 ? "wgrad" : "hbm", ms,
                       r.flops / 1e9, ms > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
   }
   if (dump) fclose(dump);
@@ -1198,7 +1211,7 @@ static unsigned long long* g_stamp = nullptr;
 static bool g_serial = false;   // octseg_debug_set_serial: one stream, no lanes (isolated kernel durations)
 // diagnostic builds only (-DOCTSEG_STAMP): device buffer of 6 u64 receiving the per-phase cycle sums
 int octseg_debug_set_stamp(unsigned long long* dev_buf) { g_stamp = dev_buf; return OCTSEG_OK; }
-int octseg_debug_set_serial(int on) { g_serial = on != 0; return OCTSEG_OK; }
+int octseg_debug_set_serial(int on) { g_serial = on != 0; g_prof_hbm = g_serial; return OCTSEG_OK; }
 
 static Geom op_geom(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int transposed) {
   Geom g{R, S, stride, pad, transposed != 0, N, H, W, Cin, 0, 0, Cout};
