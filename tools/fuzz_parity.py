@@ -1,0 +1,41 @@
+"""GPU box: random-shape train-step parity of the fp32 engine against the CPU oracle (kink-free BN biases).
+usage: fuzz_parity.py [n_cases] [seed]"""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import torch
+from oracle import create_model, DiceLoss
+from oracle.nets import randomize_bn
+from oct_segmentation_amd.engine import SegNet
+from synth import make_batch
+from test_gpu_net import _grad_report
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for k in range(n):
+    arch = ['unet', 'unetplusplus', 'linknet'][rng.integers(3)]
+    enc = ['resnet18', 'resnet34', 'resnet50'][rng.integers(3)]
+    B = int(rng.integers(2, 5)); classes = int(rng.integers(1, 5))
+    H, W = 32 * int(rng.integers(2, 8)), 32 * int(rng.integers(2, 8))
+    S = max(H, W)
+    torch.manual_seed(100 + k)
+    ref = create_model(arch, enc, classes=classes); randomize_bn(ref, 100 + k)
+    g = torch.Generator().manual_seed(200 + k)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.bias.copy_(8.0 * ((torch.rand(m.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+    ref.train()
+    net = SegNet(arch, enc, classes=classes, device='cuda', compute_dtype=torch.float32); net.load_state_dict(ref.state_dict()); net.train()
+    img, mask = make_batch(B, classes, S, seed=300 + k)
+    img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
+    z = ref(img); loss_ref = DiceLoss()(z, mask); loss_ref.backward()
+    loss, logits, stats = net.train_step_raw(img.cuda(), mask.cuda()); torch.cuda.synchronize()
+    err = (logits.cpu() - z.detach()).abs().max().item(); scale = z.detach().abs().max().item()
+    cos, worst, name = _grad_report(net.named_grads(), ref)
+    ok = err <= 2e-4 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 1e-5 and cos > 0.999999 and worst < 5e-3
+    bad += 0 if ok else 1
+    print(f'{"ok " if ok else "BAD"} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f} loss {abs(loss.item()-loss_ref.item()):.1e} cos {cos:.8f} worst {worst:.1e} ({name})', flush=True)
+print('failures', bad)
+sys.exit(1 if bad else 0)
