@@ -6,7 +6,7 @@ csrc = os.path.join(root, 'oct_segmentation_amd', 'csrc')
 src, flags = sys.argv[1], sys.argv[2].split()
 tmp = tempfile.mkdtemp()
 so = os.path.join(tmp, 'lib.so')
-srcs = [src] + [os.path.join(csrc, f) for f in ('wgrad_mfma.hip', 'elementwise.hip', 'plan.cpp')]
+srcs = [src] + [os.path.join(csrc, f) for f in ('wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
 subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-I', csrc, '-x', 'hip'] + flags + ['-o', so] + srcs, check=True)
 sys.path.insert(0, root)
 import torch
