@@ -57,9 +57,12 @@ template <> struct RowMap<true> {
 struct TilePos { int n, y0, x0, co0, w_mt, nt_idx; };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
-// private 4 MiB L2.  Every workgroup streams the whole weight set of its N tile, so the N tile is chosen
-// by XCD: an XCD then re-reads ONE N tile's weights (<= 4 MiB for every layer but the 3072-channel one)
-// from its own L2 instead of every N tile's from MALL/HBM.  Speed only -- any placement is correct.
+// private 4 MiB L2; XCD x is given a contiguous range of the work order, so that what neighbours in that order
+// share is read from HBM / MALL once per XCD.  Two orders (host choice, ConvArgs::tile_order):
+//   N-major (0): an XCD streams ONE N tile's weights -- for weight sets that do not fit an L2 (the wide decoder layers);
+//   M-major (1): the N tiles of one M tile are neighbours -- the activation window is fetched once instead of once
+//                per N tile, and the (small) weight set is L2-resident on every XCD (ResNet bottleneck shapes).
+// Speed only -- any placement is correct.
 template <int TH, int BN>
 static __device__ __forceinline__ TilePos map_tile(const ConvArgs& a) {
   const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
@@ -68,15 +71,16 @@ static __device__ __forceinline__ TilePos map_tile(const ConvArgs& a) {
   int mt_idx, nt_idx;
   {
     const int total = n_mt * n_nt;
-    const int xcd = lid & 7, seq = lid >> 3;                 // position inside this XCD's stream
-    const int per_xcd = (total + 7) >> 3;
-    // XCD x owns the global work range [x * per_xcd, (x+1) * per_xcd) of the N-major order (nt outer, mt inner)
-    int w = xcd * per_xcd + seq;
-    if (w >= total) w = lid;                                  // ragged tail: fall back to the plain order
-    const bool exact = (total & 7) == 0;
-    if (!exact) w = lid;                                      // keep the map a bijection when 8 does not divide the grid
-    nt_idx = w / n_mt;
-    mt_idx = w - nt_idx * n_mt;
+    const int full = total & ~7;                              // the part of the grid that deals evenly over the XCDs
+    int w = lid;
+    if (lid < full) w = (lid & 7) * (full >> 3) + (lid >> 3);  // XCD x owns the work range [x, x+1) * full/8; the tail keeps the plain order
+    if (a.tile_order) {   // M-major: the N tiles of one M tile are neighbours on one XCD -> its window comes from HBM once
+      mt_idx = w / n_nt;
+      nt_idx = w - mt_idx * n_nt;
+    } else {              // N-major: an XCD streams one N tile's weights
+      nt_idx = w / n_mt;
+      mt_idx = w - nt_idx * n_mt;
+    }
   }
   TilePos tp;
   tp.n = mt_idx / (tiles_x * tiles_y);
@@ -1364,6 +1368,19 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
     // (not for Cout <= 32: those workgroups are WM waves only, and two-wave workgroups measured 20-40 % slower
     //  than four-wave ones on the thin full-resolution layers)
     if ((a.ntaps == 1 || a.Cin <= kc) && WN > 1) wm_first = 2;
+    // ... except the square 64 -> 64 3x3 layers (one N tile): the 16x16 tile measured 3-10 % faster there; the K-thin
+    // dgrads of the wide concat layers (several N tiles) keep the small tile (15 % faster)
+    if (a.ntaps == 9 && a.Cin <= kc && a.Cout <= 64 && WN > 1) wm_first = 4;
+    // 33..64 output channels over several K chunks (U-Net++ x_k_3 / x_0_2 conv1: 320..896 -> 64): 8x16 tiles, two
+    // workgroups per CU, measured 7-15 % faster than one 8-wave workgroup (its waves own a single 32-channel column)
+    if (a.ntaps == 9 && a.Cin > kc && WN == 2 && NT == 1) wm_first = 2;
+    // a 16x16 grid that fits the chip in one round beats more, smaller tiles (layer4 3x3 at 22x22: 256 workgroups, 25 % faster)
+    if (a.ntaps == 9 && a.Cin > kc) {
+      const int BN = NT * 32 * WN;
+      const long long b16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) * ((a.Cout + BN - 1) / BN);
+      const long long b8 = (long long)a.N * ((a.OH + 7) / 8) * ((a.OW + TW - 1) / TW) * ((a.Cout + BN - 1) / BN);
+      if (b16 <= 256 && b8 > 256) wm_first = 4;
+    }
   }
   static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch
   if (force_wm) wm_first = force_wm;
@@ -1492,6 +1509,15 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
   if (a0.ntaps <= 0) return hipSuccess;
   ConvArgs a = a0;
   flatten_1x1(a);
+  {
+    // weight set small enough to stay in every XCD's L2 next to the windows -> M-major order (see map_tile)
+    int wt = 0;
+    for (int t = 0; t < a.ntaps; ++t) wt = a.tap_w[t] + 1 > wt ? a.tap_w[t] + 1 : wt;
+    const size_t wbytes = (size_t)wt * a.Cout * a.Cin * dtype_size(dtype);
+    static const int force = getenv("OCTSEG_TILE_ORDER") ? atoi(getenv("OCTSEG_TILE_ORDER")) : -1;   // A/B switch
+    (void)wbytes;   // measured: M-major is never slower, also when the weight set exceeds an L2 (dgrads of the wide layers: -3..14 %)
+    a.tile_order = force >= 0 ? force : 1;
+  }
   if (dtype == DT_F32) return dispatch<float>(a, st);
   return dispatch<bf16_t>(a, st);
 }

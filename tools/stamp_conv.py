@@ -31,7 +31,7 @@ print(f'stamped build: {e0.elapsed_time(e1) / 5:.3f} ms/iter')
 print(f'{N}x{H}x{W} {Cin}->{Cout} k{R}')
 n = max(1, b[5])
 names = ['issue (slab DMA, slice load)', 'MFMA block', 'vmcnt wait', 'affine + LDS store + lgkm', 'barrier']
-tot = sum(b[:5])
+tot = max(1, sum(b[:5]))
 for i in range(5):
     print(f'  {names[i]:42s} {b[i] / n:8.1f} ticks/tap  {100.0 * b[i] / tot:5.1f} %')
 print(f'  total {tot / n:.1f} ticks per wave-tap ({n} wave-taps)')
