@@ -62,6 +62,7 @@ struct ConvArgs {
   const float* bias;      // per-Cout, nullable
   float* stat_slab;       // nullable: [slab rows][Cout][2] partial (sum, sumsq) per M tile
   int slab_row0;
+  int src_uniform;        // set by launch_conv: every source starts on a K-chunk boundary (the per-chunk source choice is then scalar)
   int tile_order;         // set by launch_conv: 0 N-major, 1 M-major placement of the tiles on the XCDs (speed only)
   unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only: per-phase cycle sums, else nullptr
 };

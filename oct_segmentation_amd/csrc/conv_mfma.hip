@@ -654,19 +654,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     Stager sA, sB;
     uint4 avA[PPT], avB[PPT];
     bool okA[PPT], okB[PPT];
-    auto load_chunk = [&](Stager& sg, int chunk, uint4 (&av)[PPT], bool (&ok)[PPT]) __attribute__((always_inline)) {
-      sg.setup(a.src, a.nsrc, a.Cin, min(chunk, nchunks - 1), tid);
-      sg.bind_image(n);
+    // the image coordinates of this thread's PPT window pixels do not depend on the chunk: resolved once
+    int pyc[PPT], pxc[PPT];
+    bool pok[PPT];
+    {
       int hy = hy_first, hx = hx_first, hp = p0w;
 #pragma unroll
       for (int u = 0; u < PPT; ++u) {
-        av[u] = sg.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, ok[u]);
+        const int iy = gy0 + hy * smul, ix = gx0 + hx * smul;
+        pok[u] = hp < npix && (unsigned)iy < (unsigned)IHl && (unsigned)ix < (unsigned)IWl;
+        pyc[u] = min(max(iy, 0), IHl - 1); pxc[u] = min(max(ix, 0), IWl - 1);
         const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
         if (adv) {
           hp += Stager::PSTEP;
           hy += dq; hx += dr;
           if (hx >= RW) { hx -= RW; hy += 1; }
         }
+      }
+    }
+    const bool usrc = a.src_uniform != 0;
+    auto load_chunk = [&](Stager& sg, int chunk, uint4 (&av)[PPT], bool (&ok)[PPT]) __attribute__((always_inline)) {
+      sg.setup(a.src, a.nsrc, a.Cin, min(chunk, nchunks - 1), tid, usrc);
+      sg.bind_image(n);
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        av[u] = sg.load_xy(pyc[u], pxc[u]);
+        ok[u] = sg.cvalid && pok[u];
       }
     };
     auto body = [&](int c, Stager& sld, uint4 (&avl)[PPT], bool (&okl)[PPT], const Stager& sst, const uint4 (&avs)[PPT],
@@ -1425,10 +1438,19 @@ static Choice choose_legacy(const ConvArgs& a, int esz) {
 }
 
 template <typename T>
-hipError_t dispatch(const ConvArgs& a, hipStream_t st) {
-  const Choice c = choose(a, (int)sizeof(T));
+hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
+  const Choice c = choose(a_in, (int)sizeof(T));
   if (c.lds > 160 * 1024) return hipErrorInvalidValue;
   const Variant& v = c.v;
+  ConvArgs a = a_in;
+  {
+    const int KC = v.RB / (int)sizeof(T);
+    a.src_uniform = 1;
+    for (int i = 1; i < a.nsrc; ++i)
+      if (a.src[i].c0 % KC != 0) a.src_uniform = 0;
+    static const bool no_usrc = getenv("OCTSEG_NO_UNIFORM_SRC") != nullptr;   // A/B switch
+    if (no_usrc) a.src_uniform = 0;
+  }
   if (c.pipe) {
 #define OCTSEG_PIPE(NT_, WN_, WM_) \
     if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_) return launch_pipe<T, NT_, WN_, WM_>(a, c.pipe, c.lds, st);
