@@ -40,8 +40,11 @@ template <> struct Tr<float> {
   static __device__ __forceinline__ void store(void* p, size_t i, float v) { ((float*)p)[i] = v; }
 };
 static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-  __bf16 a = (__bf16)lo, b = (__bf16)hi;
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  // one v_cvt_pk_bf16_f32 (two scalar conversions + shift + or took four instructions)
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t x = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
 }
 template <> struct Tr<bf16_t> {
   static constexpr int VEC = 8;

@@ -121,24 +121,35 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     if (!head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
       constexpr int ES = (int)sizeof(T);
       const int lbase = (wm * 4 * TW + 4 * h) * OPITCH + (wn * NT * 32 + r) * ES;
+      // transposed tile into LDS; the bias add and the BN partial sums only where the layer has them (uniform
+      // branches: a dgrad has neither and saves three of its four vector instructions per element)
+      auto emit = [&](auto bias_c, auto stat_c) __attribute__((always_inline)) {
+        constexpr bool HAS_BIAS = decltype(bias_c)::value, HAS_STAT = decltype(stat_c)::value;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        s1[nt] = 0.f; s2[nt] = 0.f;
-        const int co = co0 + wn * NT * 32 + nt * 32 + r;
-        const bool cok = co < a.Cout;                       // lanes past Cout: their sums are never stored
-        const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        for (int nt = 0; nt < NT; ++nt) {
+          s1[nt] = 0.f; s2[nt] = 0.f;
+          float bias = 0.f;
+          if constexpr (HAS_BIAS) {
+            const int co = co0 + wn * NT * 32 + nt * 32 + r;
+            bias = co < a.Cout ? a.bias[co] : 0.f;           // lanes past Cout: their sums are never stored
+          }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+          for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float val = acc[mt][nt][i] + bias;
-            s1[nt] += val; s2[nt] += val * val;
-            const int off = ((mt * 2 + (i >> 3)) * TW + (i & 3) + 8 * ((i >> 2) & 1)) * OPITCH + nt * 32 * ES;
-            if (sizeof(T) == 4) *(float*)(otile + lbase + off) = val;
-            else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lbase + off) = __builtin_bit_cast(unsigned short, b); }
+            for (int i = 0; i < 16; ++i) {
+              float val = acc[mt][nt][i];
+              if constexpr (HAS_BIAS) val += bias;
+              if constexpr (HAS_STAT) { s1[nt] += val; s2[nt] += val * val; }
+              const int off = ((mt * 2 + (i >> 3)) * TW + (i & 3) + 8 * ((i >> 2) & 1)) * OPITCH + nt * 32 * ES;
+              if (sizeof(T) == 4) *(float*)(otile + lbase + off) = val;
+              else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lbase + off) = __builtin_bit_cast(unsigned short, b); }
+            }
           }
         }
-      }
+      };
+      using std::true_type; using std::false_type;
+      if (a.bias != nullptr) { if (a.stat_slab != nullptr) emit(true_type{}, true_type{}); else emit(true_type{}, false_type{}); }
+      else { if (a.stat_slab != nullptr) emit(false_type{}, true_type{}); else emit(false_type{}, false_type{}); }
       if (a.stat_slab != nullptr) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
