@@ -219,7 +219,8 @@ struct WindowStager {
   }
   // uniform (host: every source starts on a K-chunk boundary): the chunk lies in ONE source, which is then picked on
   // the scalar unit; otherwise every lane selects for its own channel (4 x 12 vector selects per call)
-  __device__ __forceinline__ void setup(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid, bool uniform = false) {
+  // select(): source, channel vector and validity of this thread for `chunk` -- no memory access
+  __device__ __forceinline__ void select(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid, bool uniform = false) {
     cv = tid % VPR;
     p0 = tid / VPR;
     const int c = chunk * KC + cv * VEC;
@@ -231,6 +232,10 @@ struct WindowStager {
       s = select_src(src, nsrc, cvalid ? c : 0);
     }
     has_aff = cvalid && s.scale != nullptr;
+  }
+  // setup(): select() + the lazy-BN parameters of the channel vector (plain loads: hipcc waits for them at first use)
+  __device__ __forceinline__ void setup(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid, bool uniform = false) {
+    select(src, nsrc, Cin, chunk, tid, uniform);
     if (has_aff) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { sc[i] = s.scale[s.cl + i]; sh[i] = s.shift[s.cl + i]; }

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool has_next = chunk + 1 < nchunks;
       Stager nxt;
-      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid);
+      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid, a.src_uniform != 0);
       nxt.bind_image(n);
       const char* awin = ldsA + ((DBUF && (chunk & 1)) ? abytes : 0);
       char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
@@ -740,8 +740,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool has_next = chunk + 1 < nchunks;
       Stager nxt;
-      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid);
+      nxt.select(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid, a.src_uniform != 0);
       nxt.bind_image(n);
+      // Lazy-BN parameters of that chunk: asm loads like the slices.  As plain loads hipcc waited for them at their
+      // first use, which lies inside the exec-masked affine of a tap; at the join behind it its model still held them
+      // pending, so EVERY tap's affine got an `s_waitcnt vmcnt(0)` -- which also drained the slab DMAs and the slice
+      // that tap had just issued (each tap then paid its own prefetch latency).  Issued here they are older than tap
+      // 0's prefetches, so tap 0's counted wait retires them; it names them "+v", and the first use is in tap 1.
+      u32x4_t q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0}, q3 = {0, 0, 0, 0};
+      {
+        const char* scp = nxt.has_aff ? (const char*)(nxt.s.scale + nxt.s.cl) : Wp;   // (any readable 32 bytes)
+        const char* shp = nxt.has_aff ? (const char*)(nxt.s.shift + nxt.s.cl) : Wp;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q0) : "v"(scp));
+        if constexpr (Stager::VEC == 8) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q1) : "v"(scp));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q2) : "v"(shp));
+        if constexpr (Stager::VEC == 8) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q3) : "v"(shp));
+      }
       const char* awin = ldsA + ((chunk & 1) ? abytes : 0);
       char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
       int hy = hy_first, hx = hx_first, hp = p0w;
@@ -793,8 +807,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
                 wv = nxt.prep(__builtin_bit_cast(uint4, avA), okA);
               }
             } else {
-              asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + W) : "memory");
+              asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "n"(DPW + W) : "memory");
               STAMP(s3);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                nxt.sc[i] = __uint_as_float(q0[i]); nxt.sh[i] = __uint_as_float(q2[i]);
+                if constexpr (Stager::VEC == 8) { nxt.sc[4 + i] = __uint_as_float(q1[i]); nxt.sh[4 + i] = __uint_as_float(q3[i]); }
+              }
             }
 #ifdef OCTSEG_STAMP
             tsum[2] += s3 - s2;

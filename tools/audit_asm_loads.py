@@ -1,7 +1,7 @@
 """ISA audit of conv_mfma.hip (CPU, needs hipcc): the window slices of run9r are loaded by asm global_load
-statements that hipcc does not track.  Between such a load and the asm `s_waitcnt vmcnt` that retires it (the
-second one after the load: the first belongs to the same tap and names the other register set) NO instruction may
-read or write the destination registers -- a compiler copy there reads registers still in flight.
+statements that hipcc does not track (and so are the lazy-BN parameters of a chunk).  Between such a load and the
+`s_waitcnt vmcnt(N)` that retires it (the first one with at least N memory operations issued behind the load) NO
+instruction may read or write the destination registers -- a compiler copy there reads registers still in flight.
 usage: python tools/audit_asm_loads.py   (exit code 1 on a violation)"""
 import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,16 +26,17 @@ for nm in re.findall(r'^(_ZN6octseg16conv_mfma_kernelI\S+):', s, re.M):
             loads.append((k, int(m.group(1)), int(m.group(2))))
     for k, lo, hi in loads:
         nload += 1
-        waits = 0; inasm = False
+        # vmcnt retires in issue order: `s_waitcnt vmcnt(N)` leaves at most the N youngest memory operations in flight, so
+        # a load is complete at the first wait that has at least N operations issued behind the load (M >= N)
+        younger = 0
         for q in range(k + 1, len(lines)):
             t = lines[q].strip()
-            if 'ASMSTART' in t: inasm = True; continue
-            if 'ASMEND' in t: inasm = False; continue
-            if inasm and t.startswith('s_waitcnt vmcnt'):
-                waits += 1
-                if waits == 2: break
+            if 'ASMSTART' in t or 'ASMEND' in t or t.startswith(';') or not t: continue
+            mw = re.match(r's_waitcnt .*vmcnt\((\d+)\)', t)
+            if mw:
+                if younger >= int(mw.group(1)): break
                 continue
-            if t.startswith(';') or not t: continue
+            if re.match(r'(global|buffer|scratch|flat)_', t): younger += 1
             for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', t):
                 a, b = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
                 if not (b < lo or a > hi):
