@@ -197,6 +197,9 @@ struct WindowStager {
     const unsigned off = (unsigned)((iyc >> s.up) * row_bytes + (ixc >> s.up) * pix_bytes);
     return *(const uint4*)(img_base + off);
   }
+  __device__ __forceinline__ const char* addr_xy(int iyc, int ixc) const {
+    return img_base + (unsigned)((iyc >> s.up) * row_bytes + (ixc >> s.up) * pix_bytes);
+  }
   // address half of load_at (for callers that issue the load themselves)
   __device__ __forceinline__ const char* addr_at(int hy, int hx, bool in_window, int gy0, int gx0, int smul, int IH, int IW,
                                                  bool& ok) const {

@@ -655,15 +655,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   };
   // 1x1 convs (one tap, four window passes per K chunk): the rolled loop loads a chunk's window at the top of an
   // iteration and stores it at the bottom of the same one.  Here the loads of chunk c + 2 are issued in iteration c
-  // and stored in iteration c + 1 -- a whole iteration of MFMAs later -- with two named register sets and two
-  // stagers (the lazy-BN parameters follow the chunk), written out for a pair of iterations so that no register
-  // copy is needed.  All loads are plain C++ (hipcc counts them itself); the slab DMA is issued first in an
-  // iteration, so the explicit `vmcnt(PPT)` in front of the barrier retires it and leaves only the young window
-  // loads in flight.
+  // and stored in iteration c + 1 -- a whole iteration of MFMAs later -- with two named register sets (window vectors
+  // and the lazy-BN parameters, which follow the chunk) and two stagers, written out for a pair of iterations so
+  // that no register copy is needed.  Every load is an asm statement outside hipcc's waitcnt model (as plain loads
+  // the compiler reused their destinations for the next addresses and drained vmcnt(0) once per iteration for the
+  // write-after-read): per iteration the slab DMA is issued first, then the NLD loads; the stores of chunk c + 1
+  // wait for `vmcnt(all this iteration issued)` and name their registers "+v"; `vmcnt(NLD)` in front of the barrier
+  // retires the DMA and leaves the young loads in flight.  tools/audit_asm_loads.py checks the register rule.
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   auto run1p = [&]() __attribute__((always_inline)) {
     constexpr int PPT = 4;
+    constexpr int NQ = 2 * (Stager::VEC / 4);                 // parameter vectors: scale, shift (x2 for 8 channels)
+    constexpr int NLD = PPT + NQ;                             // asm loads per chunk
+    constexpr int NDM = NDMA % NWAVES == 0 ? DPW : 0;         // DMAs EVERY wave issues per iteration (lower bound)
     Stager sA, sB;
-    uint4 avA[PPT], avB[PPT];
+    u32x4_t avA0 = {0, 0, 0, 0}, avA1 = avA0, avA2 = avA0, avA3 = avA0, qA0 = avA0, qA1 = avA0, qA2 = avA0, qA3 = avA0;
+    u32x4_t avB0 = avA0, avB1 = avA0, avB2 = avA0, avB3 = avA0, qB0 = avA0, qB1 = avA0, qB2 = avA0, qB3 = avA0;
     bool okA[PPT], okB[PPT];
     // the image coordinates of this thread's PPT window pixels do not depend on the chunk: resolved once
     int pyc[PPT], pxc[PPT];
@@ -684,43 +691,68 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       }
     }
     const bool usrc = a.src_uniform != 0;
-    auto load_chunk = [&](Stager& sg, int chunk, uint4 (&av)[PPT], bool (&ok)[PPT]) __attribute__((always_inline)) {
-      sg.setup(a.src, a.nsrc, a.Cin, min(chunk, nchunks - 1), tid, usrc);
+#define OCTSEG_LD4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+#define OCTSEG_LD4_16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(dst) : "v"(ptr))
+    auto load_chunk = [&](Stager& sg, int chunk, u32x4_t& v0, u32x4_t& v1, u32x4_t& v2, u32x4_t& v3, u32x4_t& q0, u32x4_t& q1,
+                          u32x4_t& q2, u32x4_t& q3, bool (&ok)[PPT]) __attribute__((always_inline)) {
+      sg.select(a.src, a.nsrc, a.Cin, min(chunk, nchunks - 1), tid, usrc);
       sg.bind_image(n);
+      const char* scp = sg.has_aff ? (const char*)(sg.s.scale + sg.s.cl) : Wp;   // (any readable 32 bytes)
+      const char* shp = sg.has_aff ? (const char*)(sg.s.shift + sg.s.cl) : Wp;
+      OCTSEG_LD4(q0, scp);
+      if constexpr (Stager::VEC == 8) OCTSEG_LD4_16(q1, scp);
+      OCTSEG_LD4(q2, shp);
+      if constexpr (Stager::VEC == 8) OCTSEG_LD4_16(q3, shp);
+      const char* g0 = sg.addr_xy(pyc[0], pxc[0]); OCTSEG_LD4(v0, g0);
+      const char* g1 = sg.addr_xy(pyc[1], pxc[1]); OCTSEG_LD4(v1, g1);
+      const char* g2 = sg.addr_xy(pyc[2], pxc[2]); OCTSEG_LD4(v2, g2);
+      const char* g3 = sg.addr_xy(pyc[3], pxc[3]); OCTSEG_LD4(v3, g3);
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        av[u] = sg.load_xy(pyc[u], pxc[u]);
-        ok[u] = sg.cvalid && pok[u];
-      }
+      for (int u = 0; u < PPT; ++u) ok[u] = sg.cvalid && pok[u];
     };
-    auto body = [&](int c, Stager& sld, uint4 (&avl)[PPT], bool (&okl)[PPT], const Stager& sst, const uint4 (&avs)[PPT],
-                    const bool (&oks)[PPT]) __attribute__((always_inline)) {
+    auto body = [&](int c, Stager& sld, u32x4_t& l0, u32x4_t& l1, u32x4_t& l2, u32x4_t& l3, u32x4_t& lq0, u32x4_t& lq1, u32x4_t& lq2,
+                    u32x4_t& lq3, bool (&okl)[PPT], Stager& sst, u32x4_t& s0, u32x4_t& s1, u32x4_t& s2, u32x4_t& s3, u32x4_t& sq0,
+                    u32x4_t& sq1, u32x4_t& sq2, u32x4_t& sq3, const bool (&oks)[PPT]) __attribute__((always_inline)) {
       char* wnext = ldsA + ((c & 1) ? 0 : abytes);
+      auto row = [&](int u) { return wnext + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH; };
       mma_tap_f(ldsA + ((c & 1) ? abytes : 0), ldsB + (c & 1) * BBYTES, 0,
         [&]() {   // behind k-step 0: slab of the next iteration (oldest in the queue), then the loads of chunk c + 2
           dmaB(a.tap_w[0] * nchunks + min(c + 1, nchunks - 1), (c + 1) & 1);
-          load_chunk(sld, c + 2, avl, okl);
+          load_chunk(sld, c + 2, l0, l1, l2, l3, lq0, lq1, lq2, lq3, okl);
         },
-        [&]() {   // behind k-steps 1 and 2: lazy BN + LDS stores of chunk c + 1 (loaded one iteration ago)
+        [&]() {   // behind k-steps 1 and 2: lazy BN + LDS stores of chunk c + 1 (everything the previous iteration issued has landed)
+          asm volatile("s_waitcnt vmcnt(%8)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(sq0), "+v"(sq1), "+v"(sq2), "+v"(sq3)
+                       : "n"(NDM + NLD) : "memory");
 #pragma unroll
-          for (int u = 0; u < PPT / 2; ++u) sst.write_at(wnext + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, avs[u], oks[u]);
+          for (int i = 0; i < 4; ++i) {
+            sst.sc[i] = __uint_as_float(sq0[i]); sst.sh[i] = __uint_as_float(sq2[i]);
+            if constexpr (Stager::VEC == 8) { sst.sc[4 + i] = __uint_as_float(sq1[i]); sst.sh[4 + i] = __uint_as_float(sq3[i]); }
+          }
+          sst.write_at(row(0), __builtin_bit_cast(uint4, s0), oks[0]);
+          sst.write_at(row(1), __builtin_bit_cast(uint4, s1), oks[1]);
         },
         [&]() {
-#pragma unroll
-          for (int u = PPT / 2; u < PPT; ++u) sst.write_at(wnext + (min(u, npass - 1) * Stager::PSTEP + p0w) * PITCH, avs[u], oks[u]);
+          sst.write_at(row(2), __builtin_bit_cast(uint4, s2), oks[2]);
+          sst.write_at(row(3), __builtin_bit_cast(uint4, s3), oks[3]);
         });
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPT) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
-    load_chunk(sB, 1, avB, okB);
-    for (int c = 0; c < nchunks; c += 2) {
-      body(c, sA, avA, okA, sB, avB, okB);
-      if (c + 1 < nchunks) body(c + 1, sB, avB, okB, sA, avA, okA);
+    load_chunk(sB, 1, avB0, avB1, avB2, avB3, qB0, qB1, qB2, qB3, okB);
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+      body(c, sA, avA0, avA1, avA2, avA3, qA0, qA1, qA2, qA3, okA, sB, avB0, avB1, avB2, avB3, qB0, qB1, qB2, qB3, okB);
+      body(c + 1, sB, avB0, avB1, avB2, avB3, qB0, qB1, qB2, qB3, okB, sA, avA0, avA1, avA2, avA3, qA0, qA1, qA2, qA3, okA);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c < nchunks) body(c, sA, avA0, avA1, avA2, avA3, qA0, qA1, qA2, qA3, okA, sB, avB0, avB1, avB2, avB3, qB0, qB1, qB2, qB3, okB);
+    // the (clamped, unused) loads of the last iterations are still in flight: their registers stay named until they land
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(avA0), "+v"(avA1), "+v"(avA2), "+v"(avA3), "+v"(qA0), "+v"(qA1), "+v"(qA2), "+v"(qA3),
+                 "+v"(avB0), "+v"(avB1), "+v"(avB2), "+v"(avB3), "+v"(qB0), "+v"(qB1), "+v"(qB2), "+v"(qB3) :: "memory");
+#undef OCTSEG_LD4
+#undef OCTSEG_LD4_16
   };
   // 3x3 taps, double-buffered window, THREE-slot slab ring (host: only when LDS allows): the chunk body is written
   // out tap by tap.  The window slice loaded in tap t is stored to LDS at the end of tap t + 1 -- a whole tap of
@@ -732,7 +764,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   // wait statement, so no consumer can be scheduled in front of the wait, and the two register sets are separate
   // variables of fully unrolled code.  tools/audit_asm_loads.py checks in the ISA that no instruction touches a
   // destination between its load and its wait ('asm load' rule of cdna_hip_programming.md); run it after any edit.
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   auto run9r = [&]() __attribute__((always_inline)) {
     constexpr int D = 3;
     int tap2 = D - 1, chunk2 = 0;                   // slab cursor: two iterations ahead
@@ -878,8 +909,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
     if constexpr (NDMA % NWAVES == 0 && RB == 128) run9r();
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
-    if (mode & 8) run(std::integral_constant<int, 4>{}, std::true_type{});   // A/B switch OCTSEG_NO_RUN1P
-    else run1p();
+    run1p();   // (the rolled loop is not kept as an A/B switch here: with both in one function hipcc moved the by-value ConvArgs to scratch)
   } else {
     if (dbuf) run(std::integral_constant<int, 1>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::false_type{});
@@ -1493,11 +1523,10 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
 #undef OCTSEG_PIPE
     return hipErrorInvalidValue;
   }
-  static const bool no_run1p = getenv("OCTSEG_NO_RUN1P") != nullptr;   // A/B switch
   const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
-    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf | (no_run1p ? 8 : 0), loop, c.lds, st);
+    return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, loop, c.lds, st);
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)

@@ -24,22 +24,40 @@ for nm in re.findall(r'^(_ZN6octseg16conv_mfma_kernelI\S+):', s, re.M):
         if inasm and t.startswith('global_load_dwordx4'):
             m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', t)
             loads.append((k, int(m.group(1)), int(m.group(2))))
+    labels = {l.strip().split(':')[0]: idx for idx, l in enumerate(lines) if re.match(r'\s*\.LBB\d+_\d+:', l)}
     for k, lo, hi in loads:
         nload += 1
         # vmcnt retires in issue order: `s_waitcnt vmcnt(N)` leaves at most the N youngest memory operations in flight, so
-        # a load is complete at the first wait that has at least N operations issued behind the load (M >= N)
-        younger = 0
-        for q in range(k + 1, len(lines)):
-            t = lines[q].strip()
-            if 'ASMSTART' in t or 'ASMEND' in t or t.startswith(';') or not t: continue
-            mw = re.match(r's_waitcnt .*vmcnt\((\d+)\)', t)
-            if mw:
-                if younger >= int(mw.group(1)): break
-                continue
-            if re.match(r'(global|buffer|scratch|flat)_', t): younger += 1
-            for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', t):
-                a, b = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
-                if not (b < lo or a > hi):
-                    print(f'{nm[29:52]}: load @{k} v[{lo}:{hi}] touched @{q}: {t[:70]}'); bad += 1
+        # a load is complete at the first wait that has at least N operations issued behind the load (M >= N).
+        # Every control-flow path from the load is walked (branch targets and fall-throughs) until such a wait.
+        seen = set(); flagged = set()
+        work = [(k + 1, 0)]
+        while work:
+            q, younger = work.pop()
+            while q < len(lines):
+                if (q, younger) in seen: break
+                seen.add((q, younger))
+                t = lines[q].strip(); q += 1
+                if q - 1 == k: break                                   # issued again: a new flight
+                if 'ASMSTART' in t or 'ASMEND' in t or t.startswith(';') or not t or t.startswith('.'): continue
+                mw = re.match(r's_waitcnt .*vmcnt\((\d+)\)', t)
+                if mw:
+                    if younger >= int(mw.group(1)): break
+                    continue
+                if t.startswith('s_endpgm'): break
+                mb = re.match(r's_cbranch_\w+ (\.LBB\d+_\d+)', t)
+                if mb:
+                    if mb.group(1) in labels: work.append((labels[mb.group(1)], younger))
+                    continue
+                mb = re.match(r's_branch (\.LBB\d+_\d+)', t)
+                if mb:
+                    q = labels[mb.group(1)]
+                    continue
+                if re.match(r'(global|buffer|scratch|flat)_', t): younger = min(younger + 1, 64)
+                for m in re.finditer(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', t):
+                    a, b = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
+                    if not (b < lo or a > hi) and (q - 1) not in flagged:
+                        flagged.add(q - 1)
+                        print(f'{nm[29:52]}: load @{k} v[{lo}:{hi}] touched @{q - 1}: {t[:70]}'); bad += 1
 print(f'{nload} asm loads audited, {bad} violations')
 sys.exit(1 if bad else 0)
