@@ -1,5 +1,5 @@
 """GPU box: random-shape train-step parity of the fp32 engine against the CPU oracle (kink-free BN biases).
-usage: fuzz_parity.py [n_cases] [seed]"""
+usage: fuzz_parity.py [n_cases] [seed]     (FUZZ_ONLY=k: only case k of the sequence, with the worst tensors listed)"""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -13,12 +13,15 @@ from test_gpu_net import _grad_report
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
+import os
+only = int(os.environ.get('FUZZ_ONLY', '-1'))   # re-run one case of the sequence, with per-tensor detail
 for k in range(n):
     arch = ['unet', 'unetplusplus', 'linknet'][rng.integers(3)]
     enc = ['resnet18', 'resnet34', 'resnet50'][rng.integers(3)]
     B = int(rng.integers(2, 5)); classes = int(rng.integers(1, 5))
     H, W = 32 * int(rng.integers(2, 8)), 32 * int(rng.integers(2, 8))
     S = max(H, W)
+    if only >= 0 and k != only: continue
     torch.manual_seed(100 + k)
     ref = create_model(arch, enc, classes=classes); randomize_bn(ref, 100 + k)
     g = torch.Generator().manual_seed(200 + k)
@@ -36,6 +39,17 @@ for k in range(n):
     cos, worst, name = _grad_report(net.named_grads(), ref)
     ok = err <= 2e-4 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 1e-5 and cos > 0.999999 and worst < 5e-3
     bad += 0 if ok else 1
+    if only >= 0:
+        gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
+        rows = []
+        grads = net.named_grads()
+        for nme, p in ref.named_parameters():
+            a_, b_ = grads[nme].cpu().double(), p.grad.double()
+            d = (a_ - b_).abs()
+            rows.append((d.max().item() / max(b_.abs().max().item(), 1e-3 * gmax), nme, tuple(p.shape), d.max().item(), b_.abs().max().item(),
+                         int((d > 0.1 * d.max()).sum()), int(d.argmax())))
+        rows.sort(reverse=True)
+        for r in rows[:12]: print('   ', r)
     print(f'{"ok " if ok else "BAD"} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f} loss {abs(loss.item()-loss_ref.item()):.1e} cos {cos:.8f} worst {worst:.1e} ({name})', flush=True)
 print('failures', bad)
 sys.exit(1 if bad else 0)
