@@ -14,6 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 import os
+bf16 = os.environ.get('FUZZ_DTYPE', 'fp32') == 'bf16'   # bf16 engine against the fp32 oracle: loose bounds (logits 3 %, gradient cosine 0.99)
 only = int(os.environ.get('FUZZ_ONLY', '-1'))   # re-run one case of the sequence, with per-tensor detail
 for k in range(n):
     arch = ['unet', 'unetplusplus', 'linknet'][rng.integers(3)]
@@ -30,7 +31,7 @@ for k in range(n):
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.bias.copy_(8.0 * ((torch.rand(m.bias.shape, generator=g) < 0.7).float() * 2 - 1))
     ref.train()
-    net = SegNet(arch, enc, classes=classes, device='cuda', compute_dtype=torch.float32); net.load_state_dict(ref.state_dict()); net.train()
+    net = SegNet(arch, enc, classes=classes, device='cuda', compute_dtype=torch.bfloat16 if bf16 else torch.float32); net.load_state_dict(ref.state_dict()); net.train()
     img, mask = make_batch(B, classes, S, seed=300 + k)
     img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
     z = ref(img); loss_ref = DiceLoss()(z, mask); loss_ref.backward()
@@ -38,6 +39,7 @@ for k in range(n):
     err = (logits.cpu() - z.detach()).abs().max().item(); scale = z.detach().abs().max().item()
     cos, worst, name = _grad_report(net.named_grads(), ref)
     ok = err <= 2e-4 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 1e-5 and cos > 0.999999 and worst < 5e-3
+    if bf16: ok = err <= 3e-2 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 5e-3 and cos > 0.99
     bad += 0 if ok else 1
     if only >= 0:
         gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
