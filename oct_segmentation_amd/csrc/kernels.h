@@ -83,7 +83,7 @@ hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int
 // Dice loss (multilabel, from logits) + confusion counts, logits/target NCHW f32
 struct DiceArgs {
   const float* logits; const float* target; int B, C; size_t HW;
-  double* sums;        // [C][3]: I, S, T   (zeroed by the launcher)
+  double* sums;        // [1 + B][C][3]: I, S, T totals, then per-image replicas (zeroed by the launcher)
   long long* stats;    // [B][C][4]: tp, fp, fn, tn (zeroed by the launcher), nullable
   float* loss;         // scalar
 };

@@ -558,7 +558,7 @@ static int build_plan(octseg_plan* P) {
   }
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
-  P->dice_off = off; off += align_up((size_t)P->classes * 3 * sizeof(double));
+  P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * 3 * sizeof(double));   // totals + per-image replicas
   P->ws_bytes = off;
   return OCTSEG_OK;
 }
