@@ -14,10 +14,12 @@
  *                                      (model.py:55,81,115) + smp.metrics.get_stats (utils.py:19-23)
  *   octseg_net_backward                loss.backward() that Lightning runs after training_step
  *                                      (model.py:73-95, train.py:130-133)
+ *   octseg_net_backward_sliced         the same under DDP: gradient buckets handed out while the backward still runs
+ *                                      (train.py:122-133, devices > 1)
  *   octseg_optim_step                  configure_optimizers -> SGD|RMSprop|RAdam|Adam.step()
  *                                      (model.py:150-181)
  *   octseg_augment                     OCTDataset.get_img_augmentation applied in __getitem__ (dataset.py:119-123,160-207)
- *   octseg_mask_assemble               the per-frame epilogue of segment(): threshold, PIL NEAREST resize to output_size,
+ *   octseg_mask_assemble               the per-frame epilogue of segment(): threshold, cv2 INTER_NEAREST resize to output_size,
  *                                      write into mask[:, :, CLASS_ID - 1] (src/predict.py:92-100, data/utils.py:16-33)
  *   octseg_plan_set_graph              (serving option, no reference counterpart) eval forwards of predict()
  *                                      (model.py:183-200) replayed as one hipGraph
@@ -141,8 +143,8 @@ int octseg_augment(const float* img, const float* mask, float* img_out, float* m
 /* Serving epilogue (reference src/predict.py:92-100): out[n][y][x][out_ch] = sigmoid(logits[n][ch]) > 0.5 after a nearest
  * resize from H x W to out_h x out_w.  logits: NCHW f32 [N,classes,H,W]; out: NHWC f32 [N,out_h,out_w,out_channels] (the
  * reference's 4-channel mask stack, channel = CLASS_ID - 1).  row_index[out_h] / col_index[out_w]: device int32 source
- * index of every output row / column -- the host mirror fills them with Pillow's NEAREST rule (steps accumulated in
- * double, PIL.Image.resize), so the masks equal the reference's bit for bit; null = floor((i + 0.5) * H / out_h). */
+ * index of every output row / column -- the host mirror fills them with OpenCV's INTER_NEAREST rule (resizeNN:
+ * min(floor(i * (1 / (out / in))), in - 1), what the reference's cv2.resize call computes); null = floor((i + 0.5) * H / out_h). */
 int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,
                          int out_channels, int out_ch, const int* row_index, const int* col_index, void* stream);
 
@@ -154,6 +156,17 @@ int octseg_dice_forward(octseg_plan* plan, void* workspace, const float* logits,
  * grads (fp32 arena, same layout as params) is overwritten with d(grad_scale * loss)/dparams. */
 int octseg_net_backward(octseg_plan* plan, const float* params, float* grads, void* workspace,
                         const float* logits, const float* target, float grad_scale, void* stream);
+
+/* Data-parallel variant (reference: torch DDP's bucketed gradient all-reduce overlapped with backward, which Lightning installs for
+ * src/models/smp/train.py:122-133 when more than one GPU is visible).  Same launches; the gradient arena is cut into
+ * `nslices` contiguous parameter-aligned ranges and cb(user, k, begin, end) -- element offsets into grads -- is called on the
+ * calling host thread as soon as the last launch writing into slice k is enqueued; comm_stream (not the compute stream) has by
+ * then been made to wait for those launches, so the collective the callback enqueues there overlaps the rest of the backward.
+ * Slices are reported exactly once each, in completion order (decoder / head ranges first). */
+typedef void (*octseg_slice_cb)(void* user, int slice, size_t begin, size_t end);
+int octseg_net_backward_sliced(octseg_plan* plan, const float* params, float* grads, void* workspace, const float* logits,
+                               const float* target, float grad_scale, void* stream, int nslices, void* comm_stream,
+                               octseg_slice_cb cb, void* user);
 
 /* kind: 0 SGD, 1 Adam, 2 RMSprop, 3 RAdam (torch defaults for everything not listed).
  * state_m / state_v: fp32 arenas of numel elements (may be NULL when unused by the kind). */

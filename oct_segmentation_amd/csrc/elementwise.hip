@@ -724,11 +724,15 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float g
         const float I = (float)a.sums[c * 3], S = (float)a.sums[c * 3 + 1], Tt = (float)a.sums[c * 3 + 2];
         if (Tt > 0.f) {
           const float z = a.logits[(b * a.C + c) * a.HW + i], t = a.target[(b * a.C + c) * a.HW + i];
-          const float pr = sigmoid_acc(z);
+          // dp/dz = p (1 - p) = e / (1 + e)^2 with e = exp(-|z|): autograd of logsigmoid(z).exp() gives exactly this
+          // product (p * e/(1+e) for z >= 0, p * 1/(1+e) for z < 0).  Written as p * (1 - p) it vanishes for z > ~17
+          // (p rounds to 1), which drops the gradient of every confidently-positive pixel of a saturated net.
+          const float e = expf(-fabsf(z));
+          const float dpdz = e / ((1.0f + e) * (1.0f + e));
           float dscore;  // d(2I / max(S, eps)) / dp
           if (S > 1e-7f) dscore = (2.0f * t * S - 2.0f * I) / (S * S);
           else dscore = 2.0f * t / 1e-7f;
-          d[c] = -dscore * pr * (1.0f - pr) * grad_scale / (float)a.C;
+          d[c] = -dscore * dpdz * grad_scale / (float)a.C;
         }
       }
     }
@@ -835,8 +839,8 @@ hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJ
 
 // ------------------------------------------------------------------ serving: threshold + nearest resize + mask assembly
 // out[n][y][x][out_ch] = logits[n][ch][rows[y]][cols[x]] > 0  (sigmoid(z) > 0.5).  rows / cols: source index of every
-// output row / column (the caller builds them with the resize rule it wants bit-for-bit, e.g. Pillow's accumulated
-// double steps); null tables = floor((i + 0.5) * S / O) in exact integers.
+// output row / column (the caller builds them with the resize rule it wants bit-for-bit: the host mirror passes OpenCV's
+// INTER_NEAREST table, predict.py:92-96); null tables = floor((i + 0.5) * S / O) in exact integers (identity when S == O).
 __global__ __launch_bounds__(256) void mask_assemble_kernel(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH,
                                                             int OW, int OC, int out_ch, const int* rows, const int* cols) {
   const size_t total = (size_t)N * OH * OW;
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(256) void mask_assemble_kernel(const float* logits,
     int sx = cols ? cols[x] : (int)(((long long)(2 * x + 1) * SW) / (2 * OW));
     sy = min(max(sy, 0), SH - 1); sx = min(max(sx, 0), SW - 1);
     const float z = logits[(((size_t)n * C + ch) * SH + sy) * SW + sx];
-    out[i * OC + out_ch] = z > 0.f ? 1.f : 0.f;
+    out[i * OC + out_ch] = sigmoid_acc(z) > 0.5f ? 1.f : 0.f;   // the reference's `sigmoid() > 0.5` in fp32 (model.py:195), as the Dice kernel
   }
 }
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,

@@ -906,8 +906,63 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   return OCTSEG_OK;
 }
 
-static int run_backward(Exec& E, const float* logits, const float* target, float grad_scale) {
+// Gradient-arena slices handed to the caller as soon as their last writer is enqueued (data-parallel overlap of the
+// all-reduce with the rest of the backward, octseg_net_backward_sliced).
+struct SliceCtx {
+  int n = 0;
+  hipStream_t comm = nullptr;
+  octseg_slice_cb cb = nullptr;
+  void* user = nullptr;
+  std::vector<size_t> bounds;   // n + 1 element offsets into the arena, parameter-aligned, ascending
+  std::vector<int> last_op;     // per slice: index of the op whose backward writes into it last (-1: nobody)
+};
+
+static void slice_plan(const octseg_plan* P, SliceCtx& S) {
+  const int n = S.n;
+  S.bounds.assign(n + 1, 0);
+  S.bounds[n] = P->param_numel;
+  for (int k = 1; k < n; ++k) {   // boundary k = start of the first parameter at or behind k/n of the arena
+    const size_t want = P->param_numel * (size_t)k / n;
+    size_t b = P->param_numel;
+    for (auto& q : P->params) if (q.off >= want && q.off < b) b = q.off;
+    S.bounds[k] = b;
+  }
+  for (int k = 1; k <= n; ++k) S.bounds[k] = std::max(S.bounds[k], S.bounds[k - 1]);
+  S.last_op.assign(n, -1);
+  auto touch = [&](int oi, int param) {
+    if (param < 0) return;
+    const size_t off = P->params[param].off;
+    for (int k = 0; k < n; ++k)
+      if (off >= S.bounds[k] && off < S.bounds[k + 1]) { if (S.last_op[k] < 0 || oi < S.last_op[k]) S.last_op[k] = oi; }
+  };
+  for (int oi = 0; oi < (int)P->ops.size(); ++oi) {   // the backward walks the ops downwards: the last writer has the SMALLEST index
+    const Op& op = P->ops[oi];
+    if (op.kind == OP_CONV) { touch(oi, P->convs[op.conv].w); touch(oi, P->convs[op.conv].b); }
+    else if (op.kind == OP_BN_FIN) { if (P->bns[op.bn].lazy) { touch(oi, P->bns[op.bn].gamma); touch(oi, P->bns[op.bn].beta); } }
+    else if (op.kind == OP_BN_ACT) {
+      touch(oi, P->bns[op.y.bn].gamma); touch(oi, P->bns[op.y.bn].beta);
+      if (op.res.t >= 0 && op.res.bn >= 0) { touch(oi, P->bns[op.res.bn].gamma); touch(oi, P->bns[op.res.bn].beta); }
+    }
+  }
+}
+
+static int run_backward(Exec& E, const float* logits, const float* target, float grad_scale, SliceCtx* S = nullptr) {
   octseg_plan* P = E.P;
+  if (S) slice_plan(P, *S);
+  // slice k is complete once everything enqueued so far on the dgrad stream and on the weight-gradient stream has run:
+  // the communication stream is made to wait for both, then the caller enqueues its collective there
+  auto fire = [&](int k) -> int {
+    if (S->bounds[k + 1] == S->bounds[k]) return OCTSEG_OK;
+    if (!P->ev_slice) HIPCHK(hipEventCreateWithFlags(&P->ev_slice, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(P->ev_slice, E.st));
+    HIPCHK(hipStreamWaitEvent(S->comm, P->ev_slice, 0));
+    if (E.wst && E.wst != E.st) {
+      HIPCHK(hipEventRecord(P->ev_slice, E.wst));
+      HIPCHK(hipStreamWaitEvent(S->comm, P->ev_slice, 0));
+    }
+    S->cb(S->user, k, S->bounds[k], S->bounds[k + 1]);
+    return OCTSEG_OK;
+  };
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
   HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 2 * 64 * sizeof(unsigned), E.st));
   E.ginit.assign(P->tensors.size(), 0);
@@ -980,7 +1035,13 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         break;
       }
     }
+    if (S)
+      for (int k = 0; k < S->n; ++k)
+        if (S->last_op[k] == oi) { rc = fire(k); if (rc) return rc; }
   }
+  if (S)
+    for (int k = 0; k < S->n; ++k)
+      if (S->last_op[k] < 0) { rc = fire(k); if (rc) return rc; }   // (a slice nobody writes: zeros, still part of the exchange)
   if (E.wst && E.wst != E.st) {   // join: the caller's stream owns the complete gradient arena again
     HIPCHK(hipEventRecord(P->ev_join, E.wst));
     HIPCHK(hipStreamWaitEvent(E.st, P->ev_join, 0));
@@ -1021,6 +1082,7 @@ int octseg_plan_destroy(octseg_plan* p) {
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->ev_slice) (void)hipEventDestroy(p->ev_slice);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
   }
   delete p;
@@ -1152,7 +1214,7 @@ int octseg_augment(const float* img, const float* mask, float* img_out, float* m
   return OCTSEG_OK;
 }
 
-// Serving epilogue of predict.py:92-100: sigmoid(logits[:, ch]) > 0.5, nearest resize (PIL semantics) to out_h x out_w,
+// Serving epilogue of predict.py:92-100: sigmoid(logits[:, ch]) > 0.5, nearest resize (index tables: cv2 INTER_NEAREST) to out_h x out_w,
 // written to channel out_ch of the NHWC mask stack out[N][out_h][out_w][out_channels] (f32 0/1).
 int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,
                          int out_channels, int out_ch, const int* row_index, const int* col_index, void* stream) {
@@ -1181,6 +1243,24 @@ int octseg_net_backward(octseg_plan* p, const float* params, float* grads, void*
   if (!p || !params || !grads || !workspace || !logits || !target) return fail(OCTSEG_BAD_ARG, "null argument");
   Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
   return run_backward(E, logits, target, grad_scale);
+}
+
+// Data-parallel backward: the same launches as octseg_net_backward; the gradient arena is cut into `nslices` contiguous,
+// parameter-aligned ranges and `cb(user, k, begin, end)` (element offsets) is called on the calling host thread as soon as the
+// last launch that writes into slice k has been enqueued -- `comm_stream` has by then been made to wait for it, so a collective
+// the callback enqueues on comm_stream runs beside the rest of the backward (reference: the bucketed, overlapped gradient
+// all-reduce of torch DDP that Lightning sets up, src/models/smp/train.py:122-133).  Slices complete in backward order
+// (head / decoder parameters first); every slice is reported exactly once.
+int octseg_net_backward_sliced(octseg_plan* p, const float* params, float* grads, void* workspace, const float* logits,
+                               const float* target, float grad_scale, void* stream, int nslices, void* comm_stream,
+                               octseg_slice_cb cb, void* user) {
+  if (!p || !params || !grads || !workspace || !logits || !target || !cb) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (nslices < 1 || nslices > 64) return fail(OCTSEG_BAD_ARG, "1 <= nslices <= 64 required");
+  if (!comm_stream || comm_stream == stream) return fail(OCTSEG_BAD_ARG, "comm_stream must be a stream of its own");
+  Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
+  SliceCtx S;
+  S.n = nslices; S.comm = (hipStream_t)comm_stream; S.cb = cb; S.user = user;
+  return run_backward(E, logits, target, grad_scale, &S);
 }
 
 int octseg_optim_step(int kind, float* params, const float* grads, float* m, float* v, size_t numel, float lr,

@@ -7,6 +7,8 @@ gradient arena of the same layout), a BN buffer arena and one workspace blob
 per (B, H, W) plan.  All arithmetic happens in ``liboctseg_hip.so``.
 """
 import ctypes as C
+import os
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -47,6 +49,7 @@ class _Plan:
             raise RuntimeError(msg)  # -1: same text as smp's check_input_shape RuntimeError
         self.workspace = None
         self.shape = (B, H, W)
+        self.generation = 0   # forwards run on this plan's workspace (a backward must follow ITS forward)
 
     def ws(self, device):
         if self.workspace is None:
@@ -70,14 +73,14 @@ class _DiceStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, arena, net, image, target, normalize, mean, std):
         logits, loss, stats, plan = net._forward_loss(image, target, normalize, mean, std)
-        ctx.net, ctx.plan, ctx.logits, ctx.target = net, plan, logits, target
+        ctx.net, ctx.plan, ctx.logits, ctx.target, ctx.generation = net, plan, logits, target, plan.generation
         ctx.mark_non_differentiable(logits, stats)
         return loss, logits, stats
 
     @staticmethod
     def backward(ctx, gloss, _gl, _gs):
         net = ctx.net
-        g = net._backward(ctx.plan, ctx.logits, ctx.target)
+        g = net._backward(ctx.plan, ctx.logits, ctx.target, generation=ctx.generation)
         return g * gloss, None, None, None, None, None, None
 
 
@@ -89,9 +92,20 @@ class SegNet(nn.Module):
     torchvision key names and torch weight layouts of a reference checkpoint.
     """
 
+    # smp.create_model keywords this engine implements at their smp 0.3.3 defaults only (anything else changes the graph)
+    _SMP_DEFAULTS = {'encoder_depth': 5, 'decoder_use_batchnorm': True, 'decoder_channels': (256, 128, 64, 32, 16),
+                     'decoder_attention_type': None, 'activation': None, 'aux_params': None}
+
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
                  device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
         super().__init__()
+        use_graph = bool(kwargs.pop('use_graph', False))   # eval forwards as replayed hipGraphs (serving)
+        for k, v in kwargs.items():
+            if k not in self._SMP_DEFAULTS:
+                raise TypeError(f'SegNet got an unexpected keyword argument {k!r}')
+            dflt = self._SMP_DEFAULTS[k]
+            if (tuple(v) if isinstance(v, (list, tuple)) else v) != dflt:
+                raise NotImplementedError(f'{k}={v!r}: the gfx950 engine builds the smp default ({dflt!r}) only')
         a = arch.lower()
         if a not in _ARCHS:
             raise KeyError(f'Wrong architecture type `{arch}`. Available options are: {list(_ARCHS)}')
@@ -104,7 +118,7 @@ class SegNet(nn.Module):
         self.dtype_code = _dtype_code(compute_dtype)
         self.device = torch.device(device)
         self._plans = {}
-        self.use_graph = bool(kwargs.pop('use_graph', False))   # eval forwards as replayed hipGraphs (serving)
+        self.use_graph = use_graph
         self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
         # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
         probe = _Plan(a, encoder_name, self.classes, 1, 32, 32, self.dtype_code)
@@ -129,6 +143,48 @@ class SegNet(nn.Module):
         self._grad_arena = torch.zeros(self.param_numel, dtype=torch.float32, device=self.device)
         self._by_name = {p['name']: p for p in self.param_table}
         self.initialize(seed)
+        self.load_encoder_weights(encoder_weights)
+
+    def load_encoder_weights(self, encoder_weights):
+        """``encoder_weights`` of smp.create_model.  The reference never passes it, so smp's default ``'imagenet'`` downloads
+        torchvision's ResNet weights (model.py:38-44; train.py:17 patches ssl for that download).  This engine has no network
+        path: ``None`` = random init (as ``predict.py:41``), a file path or a state_dict = torchvision ResNet weights
+        (keys ``conv1.weight``, ``layer1.0.bn1.running_mean`` ..., ``fc.*`` ignored) loaded into ``encoder.*``;
+        ``'imagenet'`` resolves to ``$OCTSEG_IMAGENET_DIR/<encoder_name>.pth`` and raises when that file is missing rather
+        than silently training from scratch."""
+        if encoder_weights is None:
+            return
+        if isinstance(encoder_weights, str) and not os.path.exists(encoder_weights):
+            root = os.environ.get('OCTSEG_IMAGENET_DIR')
+            cand = os.path.join(root, f'{self.encoder_name}.pth') if root else None
+            if cand is None or not os.path.exists(cand):
+                raise RuntimeError(
+                    f"encoder_weights={encoder_weights!r}: no pretrained weights can be downloaded here. Pass the path (or the "
+                    f"state_dict) of torchvision's {self.encoder_name} weights, or put {self.encoder_name}.pth into "
+                    f"$OCTSEG_IMAGENET_DIR; encoder_weights=None starts from random init.")
+            encoder_weights = cand
+        sd = torch.load(encoder_weights, map_location='cpu', weights_only=True) if isinstance(encoder_weights, str) else encoder_weights
+        sd = {('encoder.' + k): v for k, v in sd.items() if not k.startswith('fc.')}
+        own = {k for k in self.state_dict().keys() if k.startswith('encoder.')}
+        missing, unexpected = sorted(own - set(sd)), sorted(set(sd) - own)
+        if missing or unexpected:
+            raise RuntimeError(f'encoder weights do not fit {self.encoder_name}: missing {missing[:4]}, unexpected {unexpected[:4]}')
+        self.load_state_dict(sd, strict=False)
+
+    def _apply(self, fn, recurse=True):
+        """``.to()`` / ``.cuda()``: the arenas move with the module, so the private gradient arena, the device the plans
+        allocate on and the plans' workspaces follow; a dtype change is refused (the arenas are fp32 master copies)."""
+        super()._apply(fn, recurse)
+        if self.arena.dtype != torch.float32:
+            raise TypeError('SegNet keeps fp32 master parameters; choose the compute dtype with compute_dtype=')
+        if self.arena.device != self.device:
+            if self.arena.device.type != 'cuda':
+                raise RuntimeError('SegNet lives on the GPU (there is no CPU path)')
+            self.device = self.arena.device
+            self._grad_arena = self._grad_arena.to(self.device)
+            self._plans = {}
+            self.params_changed()
+        return self
 
     # ------------------------------------------------------------------ parameter views
     def _torch_view(self, p, arena=None):
@@ -248,6 +304,7 @@ class SegNet(nn.Module):
         x = self._check_input(x)
         B, _, H, W = x.shape
         plan = self._plan(B, H, W)
+        plan.generation += 1   # this forward overwrites the plan's saved activations / BN statistics / Dice sums
         # in-place writes to the arena (torch optimizers, copy_, all-reduce) bump its version counter; the fused
         # optimizer calls params_changed() itself.  A changed version invalidates every plan's weight images.
         ver = (self.arena._version, self._param_epoch)
@@ -300,7 +357,12 @@ class SegNet(nn.Module):
         loss, stats = self.dice(plan, logits, target)
         return logits, loss, stats, plan
 
-    def _backward(self, plan, logits, target, grad_scale=1.0):
+    def _backward(self, plan, logits, target, grad_scale=1.0, generation=None):
+        if generation is not None and generation != plan.generation:
+            raise RuntimeError(
+                f'backward of a stale step: another forward of shape {plan.shape} ran on this network since the training_step '
+                f'whose loss is being differentiated (its saved activations are gone). Call loss.backward() before the next '
+                f'forward / predict of the same shape.')
         L.check(L.lib().octseg_net_backward(plan.handle, L.ptr(self.arena.data), L.ptr(self._grad_arena),
                                             L.ptr(plan.ws(logits.device)), L.ptr(logits), L.ptr(target.contiguous()),
                                             float(grad_scale), L.stream_ptr()))
@@ -314,11 +376,16 @@ class SegNet(nn.Module):
         logits, loss, stats, _ = self._forward_loss(image, target, normalize, mean, std)
         return loss, logits, stats
 
-    def train_step_raw(self, image, target, normalize=False, mean=None, std=None, grad_scale=1.0):
+    def train_step_raw(self, image, target, normalize=False, mean=None, std=None, grad_scale=1.0, exchange=None):
         """Forward + Dice + backward without autograd: gradients land in ``grad_arena`` (and are
-        exposed as ``arena.grad`` without a copy).  The bench / DP loop uses this."""
+        exposed as ``arena.grad`` without a copy).  The bench / DP loop uses this.  ``exchange``: a
+        ``parallel.GradientExchange`` -- the backward then hands the gradient arena out slice by slice and the
+        all-reduce of each slice overlaps the rest of the backward; on return the gradients are the cross-rank sums."""
         logits, loss, stats, plan = self._forward_loss(image, target, normalize, mean, std)
-        self._backward(plan, logits, target, grad_scale)
+        if exchange is not None:
+            exchange.backward(plan, logits, target, grad_scale)
+        else:
+            self._backward(plan, logits, target, grad_scale, generation=plan.generation)
         self.arena.grad = self._grad_arena
         return loss, logits, stats
 

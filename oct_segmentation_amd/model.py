@@ -69,10 +69,13 @@ class OCTSegmentationModel(nn.Module):
 
     def __init__(self, arch, encoder_name, model_name, in_channels, classes, lr=0.0001, data_dir=None,
                  weight_decay=0.0001, optimizer_name='Adam', input_size=512, img_save_interval=1,
-                 save_wandb_media=False, device='cuda', compute_dtype=torch.bfloat16, fused_optimizer=True, **kwargs):
+                 save_wandb_media=False, device='cuda', compute_dtype=torch.bfloat16, fused_optimizer=True, encoder_weights=None,
+                 **kwargs):
         super().__init__()
-        self.model = SegNet(arch, encoder_name, in_channels=in_channels, classes=len(classes), device=device,
-                            compute_dtype=compute_dtype, **kwargs)
+        # **kwargs go to the network factory as in the reference (model.py:38-44 -> smp.create_model); SegNet rejects what it
+        # does not implement.  encoder_weights: see SegNet (the reference's smp default 'imagenet' needs a download).
+        self.model = SegNet(arch, encoder_name, encoder_weights=encoder_weights, in_channels=in_channels, classes=len(classes),
+                            device=device, compute_dtype=compute_dtype, **kwargs)
         self.classes = list(classes)
         self.data_dir = data_dir
         self.epoch = 0
@@ -126,16 +129,16 @@ class OCTSegmentationModel(nn.Module):
                'Adam': torch.optim.Adam}[self.optimizer]
         return cls(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
 
-    # ---- model.py:183-200: NHWC numpy in, no normalisation, sigmoid > 0.5, NHWC numpy out
+    # ---- model.py:183-200: NHWC numpy in, no normalisation, sigmoid > 0.5, NHWC numpy out.  The threshold and the
+    # NCHW -> NHWC transpose run in the engine's serving epilogue (octseg_mask_assemble at identity size): one D2H copy of
+    # the 0/1 masks, no torch arithmetic.
     def predict(self, images, device='cuda'):
-        x = torch.Tensor(images.transpose((0, 3, 1, 2))).to(self.model.device)
-        was_training = self.model.training
-        try:
-            y = self.model(x, normalize=False)
-        finally:
-            self.model.train(was_training)
-        masks = (y.sigmoid() > 0.5).float().cpu()
-        return masks.permute(0, 2, 3, 1).numpy().round()
+        z = self.predict_logits(images)
+        n, c, h, w = z.shape
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=z.device)
+        for ch in range(c):
+            L.check(L.lib().octseg_mask_assemble(L.ptr(z), n, c, h, w, ch, L.ptr(out), h, w, c, ch, None, None, L.stream_ptr()))
+        return out.cpu().numpy().round()
 
     def predict_logits(self, images):
         """The device half of ``predict``: NHWC numpy in, NCHW float32 logits on the GPU out (no host round trip)."""
@@ -174,7 +177,7 @@ class OCTSegmentationModel(nn.Module):
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
-        kwargs.pop('encoder_weights', None)
+        kwargs['encoder_weights'] = None   # predict.py:41 passes None: the checkpoint holds every weight
         if map_location not in (None, 'cpu'):
             kwargs.setdefault('device', map_location)
         try:

@@ -4,12 +4,70 @@ ROCm; "gloo" in the CPU tests).  Semantics are those Lightning's DDPStrategy giv
 shard of the batch with local BN statistics and a local Dice loss, gradients are averaged, BN
 buffers follow rank 0.
 
-The parameters live in ONE flat fp32 arena, so the exchange is a single all-reduce of the gradient
-arena (68 M elements = 272 MB for U-Net++/resnet101): no bucketing logic, no per-tensor launches,
-and the ring runs at the per-link xGMI rate for its whole duration.
+The parameters live in ONE flat fp32 arena (68 M elements = 272 MB for U-Net++/resnet101), so a bucket is just a
+contiguous range of it: ``GradientExchange`` asks the engine for ``nslices`` ranges (``octseg_net_backward_sliced``),
+and each range is all-reduced on a communication stream the moment its last writer is enqueued -- the head / decoder
+ranges travel over xGMI while the encoder half of the backward still computes (torch DDP's bucketed overlap, without
+per-tensor hooks or copies into bucket buffers).  ``allreduce_gradients`` is the unsliced form (one collective after
+the backward).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
+
+
+def _all_reduce_sum(t):
+    """SUM all-reduce of a (CUDA) tensor on the default group.  "nccl" (= RCCL) reduces in place on the device; the CPU
+    test backend "gloo" is fed through a host copy (independent of whether this torch build's gloo takes device tensors)."""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+class GradientExchange:
+    """Backward + gradient all-reduce of one data-parallel step, overlapped.
+
+        ex = GradientExchange(net, nslices=3)
+        loss, logits, stats = net.train_step_raw(img, mask, ..., grad_scale=1 / world, exchange=ex)
+
+    On return the caller's stream waits for every collective: ``net.arena.grad`` holds the averaged gradients."""
+
+    def __init__(self, net, nslices=3):
+        self.net, self.nslices = net, int(nslices)
+        self.comm = torch.cuda.Stream(device=net.device)
+        self.fired = []          # (slice, begin, end) in completion order of the last step (tests / diagnostics)
+        self._works = []
+        self._cb = L.SLICE_CB(self._on_slice)   # keep the ctypes thunk alive
+
+    def _on_slice(self, _user, k, begin, end):
+        self.fired.append((int(k), int(begin), int(end)))
+        g = self.net._grad_arena[begin:end]
+        with torch.cuda.stream(self.comm):
+            w = _all_reduce_sum(g)
+        if w is not None:
+            self._works.append(w)
+
+    def backward(self, plan, logits, target, grad_scale):
+        net = self.net
+        self.fired, self._works = [], []
+        cur = torch.cuda.current_stream(net.device)
+        L.check(L.lib().octseg_net_backward_sliced(plan.handle, L.ptr(net.arena.data), L.ptr(net._grad_arena),
+                                                   L.ptr(plan.ws(logits.device)), L.ptr(logits), L.ptr(target.contiguous()),
+                                                   float(grad_scale), L.stream_ptr(), self.nslices,
+                                                   C.c_void_p(self.comm.cuda_stream), self._cb, None))
+        for w in self._works:
+            w.wait()              # nccl: the current stream waits for the collective (no host block)
+        cur.wait_stream(self.comm)
+        covered = sorted((b, e) for _, b, e in self.fired)
+        assert covered[0][0] == 0 and covered[-1][1] == net.param_numel and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), \
+            'the slices reported by the engine do not tile the gradient arena'
+        return net._grad_arena
 
 
 def shard_range(n_items, rank, world):
@@ -35,7 +93,9 @@ def broadcast_buffers(net, src=0):
 def allreduce_gradients(net, world=None, average=True):
     """Sum (and average) the flat gradient arena across ranks in one collective."""
     g = net.arena.grad if net.arena.grad is not None else net._grad_arena
-    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    w = _all_reduce_sum(g)
+    if w is not None:
+        w.wait()
     if average:
         g.div_(world if world is not None else dist.get_world_size())
     return g

@@ -5,8 +5,11 @@ to that model's ``input_size``, runs ``model.predict`` frame by frame (no normal
 nearest-resizes the mask to ``output_size`` and writes channel ``MODELS_META[class]['index']`` into
 ``mask[:, :, CLASS_ID - 1]``.  Same semantics here; two deliberate host-side differences, both
 result-neutral: the FC_LC network is run once for its two classes instead of twice,
-and frames go through the engine in batches.  cv2 is absent in this image: resizing uses PIL (bilinear /
-nearest), so preprocessing agrees with the reference statistically, not bit for bit.
+and frames go through the engine in batches.  cv2 is absent in this image, so the two OpenCV resizes on the path
+are restated from OpenCV 4.8.1 (``environment.yaml:23``) ``modules/imgproc/src/resize.cpp`` in integer / double
+arithmetic: ``INTER_NEAREST`` of the predicted mask (``resizeNN``: ``min(floor(x * (1 / (dst / src))), src - 1)``) as
+index tables for the GPU epilogue, and the default 8-bit ``INTER_LINEAR`` of ``preprocessing_img`` (``resizeGeneric_``
+with 11-bit fixed-point coefficients, no antialiasing) in numpy.
 """
 import json
 import os
@@ -40,15 +43,66 @@ def load_model(model_dir, device='cuda', compute_dtype=torch.bfloat16, use_graph
     return model, cfg
 
 
+def cv2_linear_coeffs(src, dst, horizontal=True):
+    """Per output coordinate: (first tap index, second tap index, 11-bit coefficient pair) of OpenCV's 8-bit INTER_LINEAR
+    (resize.cpp ``resize_``: ``fx = (float)((dx + 0.5) * scale - 0.5)``, ``saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)``,
+    INTER_RESIZE_COEF_SCALE = 2048).  Horizontal taps that leave the row get fx = 0; the vertical table keeps its fraction
+    and clips the two row indices (resizeGeneric_Invoker)."""
+    scale = 1.0 / (dst / float(src))                      # scale_x = 1. / inv_scale_x, both double
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)      # the (float) cast
+    s0 = np.floor(f).astype(np.int64)
+    f = (f - s0.astype(np.float32)).astype(np.float32)
+    if horizontal:
+        lo = s0 < 0
+        f[lo] = 0.0; s0[lo] = 0
+        hi = s0 >= src - 1
+        f[hi] = 0.0; s0[hi] = src - 1
+    s1 = np.clip(s0 + 1, 0, src - 1)
+    s0 = np.clip(s0, 0, src - 1)
+    one = np.float32(1.0)
+    a0 = np.rint((one - f) * np.float32(2048.0)).astype(np.int64)   # cvRound: round half to even, as np.rint
+    a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    return s0, s1, a0, a1
+
+
+def cv2_resize_linear_u8(img, dst_w, dst_h):
+    """``cv2.resize(img_u8, (dst_w, dst_h))`` (default INTER_LINEAR) restated: horizontal pass in int32 with 11-bit
+    coefficients, vertical pass ``(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`` (VResizeLinear<uchar>)."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[:, :, None]
+    H, W = img.shape[:2]
+    x0, x1, ax0, ax1 = cv2_linear_coeffs(W, dst_w)
+    y0, y1, ay0, ay1 = cv2_linear_coeffs(H, dst_h, horizontal=False)
+    src = img.astype(np.int64)
+    rows = src[:, x0, :] * ax0[None, :, None] + src[:, x1, :] * ax1[None, :, None]      # [H, dst_w, C], <= 255 * 2048
+    S0, S1 = rows[y0], rows[y1]
+    out = (((ay0[:, None, None] * (S0 >> 4)) >> 16) + ((ay1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
 def preprocessing_img(img, input_size):
-    """data/utils.py:159-166: RGB -> BGR, resize to input_size (bilinear)."""
-    img = img.convert('RGB').resize((input_size, input_size), Image.BILINEAR)
-    return np.asarray(img)[:, :, ::-1].copy()
+    """data/utils.py:159-166: np.array(img) -> cvtColor RGB2BGR -> cv2.resize(image, (input_size, input_size))."""
+    image = np.asarray(img.convert('RGB'))[:, :, ::-1]
+    return cv2_resize_linear_u8(np.ascontiguousarray(image), input_size, input_size)
+
+
+def cv2_nearest_index(src, dst):
+    """Source index of every output coordinate of ``cv2.resize(..., interpolation=cv2.INTER_NEAREST)`` (predict.py:92-96).
+    OpenCV's ``resizeNN``: ``ifx = 1. / fx`` with ``fx = (double)dst / src``, ``sx = min(cvFloor(x * ifx), src - 1)`` --
+    no half-pixel centre (INTER_NEAREST_EXACT would have one; the reference does not use it)."""
+    ifx = 1.0 / (float(dst) / float(src))
+    x = np.arange(dst, dtype=np.float64)
+    return np.minimum(np.floor(x * ifx).astype(np.int64), src - 1).astype(np.int32)
 
 
 def pil_nearest_index(src, dst):
-    """Source index of every output pixel of ``PIL.Image.resize((dst, ...), NEAREST)``: Pillow steps a double by
-    src/dst from src/dst/2 and truncates, so exact-integer positions may fall on either side; same arithmetic here."""
+    """Source index of every output pixel of ``PIL.Image.resize((dst, ...), NEAREST)`` (Pillow steps a double by src/dst from
+    src/dst/2 and truncates).  NOT the rule of ``segment()`` -- kept for callers that resample label images with Pillow."""
     a0 = src / dst
     xx = a0 * 0.5
     out = np.empty(dst, dtype=np.int32)
@@ -67,8 +121,8 @@ def segment(images, masks, output_size, classes, models_dir, device='cuda', batc
     assembled 0/1 stack at the end instead of one logits tensor per frame and class."""
     from . import _lib as L
     n = len(images)
-    # PIL sizes are (width, height); the reference allocates masks as [output_size[0], output_size[1], 4] and resizes
-    # to tuple(output_size): it only ever uses square sizes, and so do the extents below
+    # cv2 sizes are (width, height); the reference allocates masks as [output_size[0], output_size[1], 4] and resizes
+    # to tuple(output_size): the assignment into mask[:, :, c] only works for square sizes, and so do the extents below
     oh, ow = masks[0].shape[0], masks[0].shape[1]
     stack = torch.zeros((n, oh, ow, 4), dtype=torch.float32, device=device)
     cache, tables = {}, {}
@@ -84,9 +138,9 @@ def segment(images, masks, output_size, classes, models_dir, device='cuda', batc
         z = cache[model_dir]
         ch = meta['index'] if z.shape[1] > 1 else 0
         key = (z.shape[2], z.shape[3])
-        if key not in tables:   # PIL size = (width, height) = tuple(output_size): columns follow output_size[0]
-            tables[key] = (torch.from_numpy(pil_nearest_index(z.shape[2], oh)).to(device),
-                           torch.from_numpy(pil_nearest_index(z.shape[3], ow)).to(device))
+        if key not in tables:   # cv2.resize(predict_mask, tuple(output_size), INTER_NEAREST): resizeNN's row / column tables
+            tables[key] = (torch.from_numpy(cv2_nearest_index(z.shape[2], oh)).to(device),
+                           torch.from_numpy(cv2_nearest_index(z.shape[3], ow)).to(device))
         rows, cols = tables[key]
         L.check(L.lib().octseg_mask_assemble(L.ptr(z), n, z.shape[1], z.shape[2], z.shape[3], int(ch), L.ptr(stack), oh, ow, 4,
                                              CLASS_IDS[class_name] - 1, L.ptr(rows), L.ptr(cols), L.stream_ptr()))

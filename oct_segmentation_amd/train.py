@@ -25,16 +25,29 @@ def write_model_config(cfg, model_dir):
 
 def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, augment_seed=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('WORLD_SIZE > 1: initialise torch.distributed (backend "nccl" = RCCL) and set the CUDA device of this '
+                               'rank before fit(); every rank passes ITS shard of the batches (parallel.shard_range)')
+        if dist.get_world_size() != world:
+            raise RuntimeError(f'WORLD_SIZE={world} but the process group has {dist.get_world_size()} ranks')
     dt = torch.float32 if str(cfg.get('compute_dtype', 'bf16')) in ('fp32', 'float32') else torch.bfloat16
     model = OCTSegmentationModel(cfg['architecture'], cfg['encoder'], f"{cfg['architecture']}_{cfg['encoder']}", 3,
                                  cfg['classes'], lr=cfg['lr'], weight_decay=cfg['weight_decay'],
                                  optimizer_name=cfg['optimizer'], input_size=cfg['input_size'], device=device, compute_dtype=dt)
     net = model.model
+    exchange = None
     if world > 1:
         parallel.broadcast_parameters(net)
+        exchange = parallel.GradientExchange(net, nslices=int(cfg.get('allreduce_slices', 3)))
     opt = model.configure_optimizers()
     history = []
     aug_rng = None
+    rank0 = int(os.environ.get('RANK', '0')) == 0
+    best_val = None   # ModelCheckpoint(monitor='val/loss', mode='min', save_top_k=1, filename='weights'), train.py:67-76
+    if model_dir is not None and rank0:
+        write_model_config(cfg, model_dir)   # the reference writes config.json before trainer.fit (train.py:105-119)
     for epoch in range(1, int(cfg['epochs']) + 1):
         model.train()
         model.training_step_outputs.clear()
@@ -45,28 +58,33 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
                 img, mask = augment_mod.augment(img, mask, augment_mod.sample_params(img.shape[0], img.shape[-1], aug_rng))
             if world > 1:
                 parallel.broadcast_buffers(net)
+            # grad_scale = 1/W inside the backward + SUM all-reduce = DDP's gradient mean; the all-reduce runs slice by
+            # slice beside the backward (parallel.GradientExchange)
             loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
-                                                     grad_scale=1.0 / world)
-            if world > 1:
-                parallel.allreduce_gradients(net, world, average=False)
+                                                     grad_scale=1.0 / world, exchange=exchange)
             opt.step()
             from .metrics import get_metrics_from_stats
             model.training_step_outputs.append(get_metrics_from_stats(stats, loss))
         row = {'epoch': epoch, 'train': aggregate_epoch(model.training_step_outputs)}
-        rank0 = int(os.environ.get('RANK', '0')) == 0
         if model_dir is not None and rank0:   # model.py:97-106: metrics.csv rows of the train split
             save_metrics_on_epoch(model.training_step_outputs, 'train', model_dir, cfg['classes'], epoch)
         if val_batches is not None:
             model.eval()
             model.validation_step_outputs.clear()
+            vsum, vcount = 0.0, 0
             for batch in val_batches:
-                model.validation_step(batch)
+                out = model.validation_step(batch)
+                vsum += float(out['val/loss']) * batch[0].shape[0]   # self.log('val/loss', on_epoch=True): batch-size-weighted mean
+                vcount += batch[0].shape[0]
+            row['val/loss'] = vsum / max(vcount, 1)
+            if model_dir is not None and rank0 and (best_val is None or row['val/loss'] < best_val):
+                best_val = row['val/loss']      # only the best-validation-loss epoch is kept, as predict.py then loads it
+                model.save_checkpoint(os.path.join(model_dir, 'weights.ckpt'), epoch=epoch)
             row['test'] = aggregate_epoch(model.validation_step_outputs)   # the reference calls the split 'test'
             if model_dir is not None and rank0:   # model.py:134-148: test rows + best metrics
                 _, model.validation_best_metrics = save_metrics_on_epoch(model.validation_step_outputs, 'test', model_dir, cfg['classes'],
                                                                          epoch, model.validation_best_metrics)
         history.append(row)
-    if model_dir is not None and int(os.environ.get('RANK', '0')) == 0:
-        write_model_config(cfg, model_dir)
+    if model_dir is not None and rank0 and val_batches is None:   # nothing to monitor: keep the last epoch
         model.save_checkpoint(os.path.join(model_dir, 'weights.ckpt'), epoch=len(history))
     return model, history

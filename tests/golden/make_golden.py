@@ -30,6 +30,16 @@ CASES = {
     'linknet_resnet50': ('linknet', 'resnet50', 2, 2, 64, 111),
     'unet_resnet18_96x64': ('unet', 'resnet18', 2, 2, (96, 64), 112),
     'c1_unet_resnet18_256': ('unet', 'resnet18', 1, 2, 256, 116),
+    # the encoder of BASELINE config c2 (U-Net++ / resnet101: 23 bottlenecks in layer3), tiny frame
+    'unetplusplus_resnet101': ('unetplusplus', 'resnet101', 1, 2, 64, 120),
+}
+# Lightning-DDP semantics (reference train.py:122-133 with devices > 1): the global batch is split
+# into `world` contiguous shards, every rank runs forward + Dice + backward on ITS shard with local BatchNorm statistics
+# and a local Dice loss, the gradients are averaged, BN running buffers follow rank 0.
+DDP_CASES = {
+    # name: (arch, encoder, classes, global batch, size, seed, world)
+    'ddp_unet_resnet18_w2': ('unet', 'resnet18', 2, 4, 64, 130, 2),
+    'ddp_linknet_resnet50_w4': ('linknet', 'resnet50', 2, 8, 64, 131, 4),
 }
 # cases larger than this many logits store a centre crop + checksums instead of the full tensor
 FULL_LOGITS_MAX = 64 * 1024
@@ -88,11 +98,50 @@ def run_case(arch, enc, classes, B, S, seed):
             'stats': torch.stack([tp, fp, fn, tn], dim=-1).numpy()}
 
 
+def shard_range(n_items, rank, world):
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def run_ddp_case(arch, enc, classes, B, S, seed, world):
+    """Sequential emulation of `world` DDP ranks on the oracle."""
+    from oracle import DiceLoss, get_stats
+    img, mask = case_batch(B, classes, S, seed)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    losses, stats, acc, rank0_buffers = [], [], None, None
+    for r in range(world):
+        m = build(arch, enc, classes, seed)          # every rank starts from rank 0's parameters and buffers
+        lo, hi = shard_range(B, r, world)
+        logits = m((img[lo:hi] - mean) / std)
+        loss = DiceLoss()(logits, mask[lo:hi])
+        loss.backward()
+        g = [p.grad / world for _, p in m.named_parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        losses.append(float(loss.item()))
+        tp, fp, fn, tn = get_stats((logits.detach().sigmoid() > 0.5).long(), mask[lo:hi].long())
+        stats.append(torch.stack([tp, fp, fn, tn], dim=-1).numpy())
+        if r == 0:
+            rank0_buffers = np.array([[b.double().sum().item(), b.double().abs().sum().item()] for n, b in m.named_buffers()
+                                      if n.endswith('running_mean') or n.endswith('running_var')])
+    return {'losses': np.array(losses), 'stats': np.concatenate(stats, axis=0),
+            'grad_abs_sums': np.array([a.abs().sum().item() for a in acc], dtype=np.float64),
+            'grad_sums': np.array([a.double().sum().item() for a in acc], dtype=np.float64),
+            'rank0_buffer_sums': rank0_buffers}
+
+
 if __name__ == '__main__':
+    for name, case in DDP_CASES.items():
+        if os.path.exists(os.path.join(HERE, f'{name}.npz')) and '--all' not in sys.argv:
+            continue
+        out = run_ddp_case(*case)
+        np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+        print(name, 'losses', out['losses'])
     for name, case in CASES.items():
-        out = run_case(*case)
         if os.path.exists(os.path.join(HERE, f'{name}.npz')) and '--all' not in sys.argv:
             continue   # committed vectors are only regenerated on request
+        out = run_case(*case)
         np.savez_compressed(os.path.join(HERE, f'{name}.npz'), loss=np.float64(out['loss']), grad_abs_sums=out['grad_abs_sums'],
                             stats=out['stats'], **summarize_logits(out['logits']))
         print(name, 'loss', out['loss'], 'logits', out['logits'].shape)

@@ -116,17 +116,17 @@ def test_segment_ensemble_channel_mapping(cuda, tmp_path):
     from oct_segmentation_amd.predict import load_model, preprocessing_img
     model, cfg = load_model(os.path.join(tmp_path, 'FC_LC'), 'cuda', torch.float32)
     p = model.predict(np.array([preprocessing_img(images[0], 64)]), 'cuda')[0]
-    lc = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
-    fc = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((96, 96), Image.NEAREST)) / 255.0
-    assert np.array_equal(out[0][:, :, 2], lc) and np.array_equal(out[0][:, :, 1], fc)
-    # the GPU threshold + nearest resize (octseg_mask_assemble) follows PIL's index rule when shrinking and for odd ratios too
+    # the reference resizes the predicted mask with cv2.resize(..., INTER_NEAREST) (predict.py:92-96): the oracle's resizeNN
+    from oracle.cv2_resize import resize_nn
+    r = resize_nn(p, (96, 96))
+    assert np.array_equal(out[0][:, :, 2], r[:, :, 0]) and np.array_equal(out[0][:, :, 1], r[:, :, 1])
+    # shrinking and odd ratios too
     for osz in (48, 37, 100):
         masks2 = [np.zeros((osz, osz, 4)) for _ in images]
         out2 = segment(images, masks2, [osz, osz], ['Lipid core', 'Fibrous cap'], str(tmp_path), device='cuda',
                        compute_dtype=torch.float32)
-        lc2 = np.asarray(Image.fromarray((p[:, :, 0] * 255).astype(np.uint8)).resize((osz, osz), Image.NEAREST)) / 255.0
-        fc2 = np.asarray(Image.fromarray((p[:, :, 1] * 255).astype(np.uint8)).resize((osz, osz), Image.NEAREST)) / 255.0
-        assert np.array_equal(out2[0][:, :, 2], lc2) and np.array_equal(out2[0][:, :, 1], fc2), osz
+        r2 = resize_nn(p, (osz, osz))
+        assert np.array_equal(out2[0][:, :, 2], r2[:, :, 0]) and np.array_equal(out2[0][:, :, 1], r2[:, :, 1]), osz
         assert not out2[0][:, :, 0].any() and not out2[0][:, :, 3].any()   # classes that were not asked for stay empty
 
 

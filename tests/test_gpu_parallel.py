@@ -1,0 +1,144 @@
+"""Data parallelism of the ENGINE (not just the host protocol, which tests/test_parallel.py covers on CPU).
+
+Lightning-DDP semantics of the reference (src/models/smp/train.py:122-133, devices > 1): every rank
+runs forward + Dice + backward on its shard with LOCAL BatchNorm statistics and a LOCAL Dice loss, gradients are averaged,
+BN running buffers follow rank 0.  The expected numbers are committed fixtures produced by the CPU oracle emulating the
+ranks one after the other (tests/golden/make_golden.py, DDP_CASES).
+
+  * test_engine_reproduces_ddp_sharded_fixtures: the ranks emulated sequentially on one GPU (world 2 and 4).
+  * test_two_ranks_one_gpu_real_process_group: two real processes on ONE GPU, torch.distributed over gloo, the engine's
+    sliced backward (octseg_net_backward_sliced) with the all-reduce of every slice issued from its callback, fused optimizer
+    step -- both ranks must hold the fixture's averaged gradients and identical parameters afterwards.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _check_against_fixture(g, names, grads, losses, stats, rank0_sd):
+    gsum = np.array([grads[n].double().sum().item() for n in names])
+    gabs = np.array([grads[n].double().abs().sum().item() for n in names])
+    rel = np.abs(gabs - g['grad_abs_sums']) / np.maximum(g['grad_abs_sums'], 1e-3 * g['grad_abs_sums'].max())
+    assert rel.max() < 2e-3, f'sum|grad| deviates by {rel.max():.2e}'
+    assert np.abs(gsum - g['grad_sums']).max() <= 2e-3 * g['grad_abs_sums'].max()
+    assert np.abs(np.array(losses) - g['losses']).max() <= 1e-5
+    if stats is not None:
+        assert np.array_equal(stats, g['stats'])
+    if rank0_sd is not None:
+        got = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for k, v in rank0_sd.items()
+                        if k.endswith('running_mean') or k.endswith('running_var')])
+        assert np.abs(got - g['rank0_buffer_sums']).max() <= 1e-4 * max(1.0, np.abs(g['rank0_buffer_sums']).max())
+
+
+@pytest.mark.parametrize('name', ['ddp_unet_resnet18_w2', 'ddp_linknet_resnet50_w4'])
+def test_engine_reproduces_ddp_sharded_fixtures(cuda, name):
+    from golden.make_golden import DDP_CASES, build, case_batch, shard_range
+    from oct_segmentation_amd.engine import SegNet
+    arch, enc, classes, B, S, seed, world = DDP_CASES[name]
+    g = np.load(os.path.join(GOLDEN, f'{name}.npz'))
+    ref = build(arch, enc, classes, seed)
+    img, mask = case_batch(B, classes, S, seed)
+    net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32).train()
+    acc, losses, stats, rank0_sd = None, [], [], None
+    for r in range(world):
+        net.load_state_dict(ref.state_dict())      # every rank starts from rank 0's parameters and buffers
+        lo, hi = shard_range(B, r, world)
+        loss, logits, st = net.train_step_raw(img[lo:hi].to(cuda), mask[lo:hi].to(cuda), normalize=True, mean=MEAN, std=STD,
+                                              grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        acc = net._grad_arena.clone() if acc is None else acc + net._grad_arena
+        losses.append(loss.item()); stats.append(st.cpu().numpy())
+        if r == 0:
+            rank0_sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    net._grad_arena.copy_(acc)
+    net.arena.grad = net._grad_arena
+    grads = {k: v.cpu() for k, v in net.named_grads().items()}
+    _check_against_fixture(g, [n for n, _ in ref.named_parameters()], grads, losses, np.concatenate(stats, axis=0), rank0_sd)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from golden.make_golden import DDP_CASES, build, case_batch, shard_range
+        from oct_segmentation_amd import parallel as P
+        from oct_segmentation_amd.engine import SegNet
+        from oct_segmentation_amd.model import FusedOptimizer
+        arch, enc, classes, B, S, seed, _ = DDP_CASES['ddp_unet_resnet18_w2']
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda:0')
+        net = SegNet(arch, enc, classes=classes, device=dev, compute_dtype=torch.float32, seed=1000 + rank).train()   # ranks differ ...
+        if rank == 0:
+            net.load_state_dict(build(arch, enc, classes, seed).state_dict())
+        P.broadcast_parameters(net)                                                                           # ... until DDP construction
+        img, mask = case_batch(B, classes, S, seed)
+        lo, hi = shard_range(B, rank, world)
+        ex = P.GradientExchange(net, nslices=3)
+        P.broadcast_buffers(net)
+        loss, logits, st = net.train_step_raw(img[lo:hi].to(dev), mask[lo:hi].to(dev), normalize=True, mean=MEAN, std=STD,
+                                              grad_scale=1.0 / world, exchange=ex)
+        torch.cuda.synchronize()
+        grads = {k: v.cpu() for k, v in net.named_grads().items()}
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        opt = FusedOptimizer(net, 'Adam', 1e-3, 1e-4)
+        opt.step()
+        torch.cuda.synchronize()
+        arena = net.arena.data.cpu()
+        other = arena.clone()
+        dist.broadcast(other, 0)
+        q.put((rank, loss.item(), st.cpu().numpy(), grads, sd if rank == 0 else None, list(ex.fired), bool(torch.equal(arena, other))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_real_process_group(cuda):
+    import torch.multiprocessing as mp
+    from golden.make_golden import DDP_CASES, build
+    arch, enc, classes, B, S, seed, world = DDP_CASES['ddp_unet_resnet18_w2']
+    g = np.load(os.path.join(GOLDEN, 'ddp_unet_resnet18_w2.npz'))
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get()
+        res[item[0]] = item
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    names = [n for n, _ in build(arch, enc, classes, seed).named_parameters()]
+    losses = [res[r][1] for r in range(world)]
+    stats = np.concatenate([res[r][2] for r in range(world)], axis=0)
+    for r in range(world):   # after the exchange EVERY rank holds the averaged gradients
+        _check_against_fixture(g, names, res[r][3], losses, stats, res[0][4] if r == 0 else None)
+        fired = res[r][5]
+        assert len(fired) == 3 and sorted(k for k, _, _ in fired) == [0, 1, 2]
+        assert fired[0][0] == 2, f'the highest arena range (decoder / head) must complete first, got {fired}'
+        assert res[r][6], 'parameters diverged between the ranks after the optimizer step'
+    for n in names:
+        assert torch.equal(res[0][3][n], res[1][3][n]), n

@@ -114,15 +114,54 @@ def test_metrics_from_stats_match_oracle():
         assert ours[k] == pytest.approx(ref[k], rel=1e-6, abs=1e-9), k
 
 
+def test_cv2_nearest_index_is_opencv_resizeNN():
+    """segment()'s mask resize is cv2.resize(..., INTER_NEAREST) (reference src/predict.py:92-96): the index tables handed to
+    octseg_mask_assemble equal the oracle's scalar restatement of OpenCV's resizeNN bit for bit -- including the sizes the
+    reference runs (704 -> 1000, 512 -> 1000) and the dataset's 704 -> 750 -- and differ from Pillow's centre rule."""
+    import numpy as np
+    from oracle.cv2_resize import resize_nn
+    from oct_segmentation_amd.predict import cv2_nearest_index, pil_nearest_index
+    for src, dst in ((704, 1000), (512, 1000), (704, 750), (64, 96), (64, 48), (64, 37), (100, 33), (37, 100), (896, 1000), (7, 7)):
+        ramp = np.arange(src, dtype=np.float32)
+        want_cols = resize_nn(np.tile(ramp, (2, 1)), (dst, 2))[0].astype(np.int64)          # dsize = (width, height)
+        want_rows = resize_nn(np.tile(ramp[:, None], (1, 2)), (2, dst))[:, 0].astype(np.int64)
+        got = cv2_nearest_index(src, dst)
+        assert got.dtype == np.int32 and np.array_equal(got, want_cols) and np.array_equal(got, want_rows), (src, dst)
+        assert got[0] == 0 and got.max() <= src - 1
+    assert (cv2_nearest_index(704, 1000) != pil_nearest_index(704, 1000)).sum() > 300   # the two rules are not interchangeable
+    # a 2-D mask through the tables == the oracle's resizeNN of the mask
+    rng = np.random.default_rng(3)
+    m = (rng.random((64, 48, 2)) > 0.5).astype(np.float32)
+    assert np.array_equal(m[cv2_nearest_index(64, 100)][:, cv2_nearest_index(48, 75)], resize_nn(m, (75, 100)))
+
+
+def test_cv2_linear_u8_matches_oracle_loops():
+    """preprocessing_img's cv2.resize(image_u8, (S, S)) (reference src/data/utils.py:159-166): the vectorised numpy tables against the
+    oracle's scalar restatement of OpenCV's fixed-point bilinear, up- and down-scaling, odd sizes; identity is exact."""
+    import numpy as np
+    from PIL import Image
+    from oracle.cv2_resize import resize_linear_u8
+    from oct_segmentation_amd.predict import cv2_resize_linear_u8, preprocessing_img
+    rng = np.random.default_rng(0)
+    for (h, w, dh, dw) in ((20, 30, 17, 23), (20, 30, 41, 37), (75, 75, 64, 64), (13, 7, 26, 14), (50, 50, 32, 32)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(cv2_resize_linear_u8(a, dw, dh), resize_linear_u8(a, (dw, dh))), (h, w, dh, dw)
+    a = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    assert np.array_equal(cv2_resize_linear_u8(a, 32, 32), a)
+    out = preprocessing_img(Image.fromarray(a), 32)
+    assert out.dtype == np.uint8 and np.array_equal(out, a[:, :, ::-1])            # RGB -> BGR, same size: untouched
+    flat = np.full((40, 40, 3), 200, np.uint8)
+    assert (cv2_resize_linear_u8(flat, 64, 64) == 200).all()
+
+
 def test_pil_nearest_index_table_is_pillows_rule():
-    """The index tables handed to octseg_mask_assemble reproduce PIL.Image.resize(..., NEAREST) exactly, including the
-    positions that fall on an integer (Pillow accumulates the step in double and truncates)."""
+    """pil_nearest_index (kept for Pillow-resampled label images; NOT segment()'s rule) reproduces PIL.Image.resize(..., NEAREST)."""
     import numpy as np
     from PIL import Image
     from oct_segmentation_amd.predict import pil_nearest_index
-    for src in (64, 224, 512, 704, 100, 37):
+    for src in (64, 704, 37):
         img = Image.fromarray(np.tile(np.arange(src, dtype=np.float32), (2, 1)))
-        for dst in (96, 48, 37, 100, 704, 512, 300, 33, 63, 65, 1000):
+        for dst in (96, 37, 1000):
             want = np.asarray(img.resize((dst, 2), Image.NEAREST))[0].astype(np.int64)
             assert np.array_equal(pil_nearest_index(src, dst), want), (src, dst)
 
