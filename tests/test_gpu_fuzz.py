@@ -40,18 +40,36 @@ def _cases(n, seed):
     return out
 
 
-def _build(k, arch, enc, classes):
+def _build(k, arch, enc, classes, residual_safe=False):
+    """BN biases at +-8: a pre-activation relu(bn(y)) is then >= ~4 sigma away from its kink.  That does NOT cover the residual
+    adds relu(bn(y) + identity) -- the identity is an unbounded non-negative tensor, so bias -8 + identity ~ 8 lands on the kink.
+    residual_safe=True gives every block-final BatchNorm (BasicBlock bn2, Bottleneck bn3, downsample.1) bias +8: block outputs
+    are then always-on and the whole net is smooth in the rounding."""
     from oracle import create_model
     from oracle.nets import randomize_bn
     torch.manual_seed(100 + k)
     ref = create_model(arch, enc, classes=classes)
     randomize_bn(ref, 100 + k)
     g = torch.Generator().manual_seed(200 + k)
+    last = 'bn3' if enc in ('resnet50', 'resnet101') else 'bn2'
     with torch.no_grad():
-        for m in ref.modules():
+        for name, m in ref.named_modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.bias.copy_(8.0 * ((torch.rand(m.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+                if residual_safe and name.startswith('encoder.layer') and (name.endswith('.' + last) or name.endswith('downsample.1')):
+                    m.bias.fill_(8.0)
     return ref.train()
+
+
+def _near_kinks(ref64, img64, reach=5e-5):
+    """Number of ReLU inputs of the float64 oracle within fp32-rounding reach of 0 (terms of magnitude ~16 summed over ~50 layers)."""
+    hits = []
+    hooks = [m.register_forward_pre_hook(lambda mod, inp: hits.append(int((inp[0].detach().abs() < reach).sum())))
+             for m in ref64.modules() if isinstance(m, torch.nn.ReLU)]
+    z = ref64(img64)
+    for h in hooks:
+        h.remove()
+    return sum(hits), z
 
 
 def _inputs(k, B, classes, H, W):
@@ -106,16 +124,54 @@ def test_fuzz_train_step_fp32(cuda, case):
         return
     # ---- triage against the exact gradient (float64 oracle, same weights / inputs)
     ref64 = _build(k, arch, enc, classes).double()
-    DiceLoss()(ref64(img.double()), mask.double()).backward()
+    near, z64 = _near_kinks(ref64, img.double())
+    DiceLoss()(z64, mask.double()).backward()
     truth = {n: p.grad for n, p in ref64.named_parameters()}
     gmax = max(t.abs().max().item() for t in truth.values())
     o32 = {n: p.grad for n, p in ref.named_parameters()}
     w_eng, n_eng = _worst_vs(grads, truth, gmax)
     w_o32, n_o32 = _worst_vs(o32, truth, gmax)
     c_eng, c_o32 = _cos(grads, truth), _cos(o32, truth)
-    print(f'   vs float64: engine worst {w_eng:.2e} ({n_eng}) cos {c_eng:.9f} | fp32 oracle worst {w_o32:.2e} ({n_o32}) cos {c_o32:.9f}')
-    assert w_eng <= max(5e-3, 4.0 * w_o32), f'engine gradient {n_eng} is {w_eng:.2e} from float64, the fp32 oracle only {w_o32:.2e}'
-    assert 1.0 - c_eng <= max(1e-6, 4.0 * (1.0 - c_o32))
+    print(f'   vs float64: engine worst {w_eng:.2e} ({n_eng}) cos {c_eng:.9f} | fp32 oracle worst {w_o32:.2e} ({n_o32}) cos {c_o32:.9f} | '
+          f'{near} ReLU inputs within 5e-5 of the kink')
+    if near == 0:   # smooth point: the engine may be a few times further from the exact gradient than the fp32 oracle, no more
+        assert w_eng <= max(5e-3, 4.0 * w_o32), f'engine gradient {n_eng} is {w_eng:.2e} from float64, the fp32 oracle only {w_o32:.2e}'
+        assert 1.0 - c_eng <= max(1e-6, 4.0 * (1.0 - c_o32))
+    else:
+        # a ReLU input (a residual add: see _build) within rounding reach of 0: its mask may legitimately differ between two fp32
+        # implementations, and one flipped pixel of a 16 x 8 x B map moves that channel's gradients by ~1 / (128 B).  Bounded, not
+        # excused: a flip cannot move the global cosine; test_fuzz_residual_safe_fp32 runs the same shapes without such kinks
+        assert w_eng <= 3e-2 and c_eng >= 0.99999, f'{n_eng}: {w_eng:.2e}, cosine {c_eng:.7f} with {near} near-kink inputs'
+
+
+_SAFE = [c for c in _cases(80, FUZZ_SEED) if c[2] == 'resnet50'][:12]
+
+
+@pytest.mark.parametrize('case', _SAFE, ids=[f'k{c[0]}-{c[1]}-{c[2]}-B{c[3]}-C{c[4]}-{c[5]}x{c[6]}' for c in _SAFE])
+def test_fuzz_residual_safe_fp32(cuda, case):
+    """The bottleneck-encoder shapes of the sequence with block-final BN biases at +8 (no ReLU input can reach its kink, residual
+    adds included): every parameter gradient within 2e-3 of its largest element, cosine 1 - 1e-6 -- the bound the 18/34-layer
+    nets meet.  This is the experiment that separates 'ReLU mask flipped at a residual add' from 'the engine is imprecise on
+    bottleneck nets' for the out-of-bound cases of test_fuzz_train_step_fp32 (k = 17, 31 of the sequence)."""
+    from oracle import DiceLoss
+    from oct_segmentation_amd.engine import SegNet
+    k, arch, enc, B, classes, H, W = case
+    ref = _build(k, arch, enc, classes, residual_safe=True)
+    net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32)
+    net.load_state_dict(ref.state_dict())
+    net.train()
+    img, mask = _inputs(k, B, classes, H, W)
+    z = ref(img)
+    loss_ref = DiceLoss()(z, mask)
+    loss_ref.backward()
+    loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    err = (logits.cpu() - z.detach()).abs().max().item()
+    scale = z.detach().abs().max().item()
+    cos, worst, name = _grad_report(net.named_grads(), ref)
+    print(f'k={k} residual-safe {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f} cos {cos:.8f} worst {worst:.1e} ({name})')
+    assert err <= 2e-4 * max(1.0, scale) and abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert cos > 0.999999 and worst < 2e-3
 
 
 _BF16 = _cases(N_BF16, FUZZ_SEED + 1)

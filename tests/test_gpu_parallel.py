@@ -24,19 +24,24 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
 
-def _check_against_fixture(g, names, grads, losses, stats, rank0_sd):
-    gsum = np.array([grads[n].double().sum().item() for n in names])
-    gabs = np.array([grads[n].double().abs().sum().item() for n in names])
+def _grad_sums(names, grads):
+    return (np.array([grads[n].double().sum().item() for n in names]), np.array([grads[n].double().abs().sum().item() for n in names]))
+
+
+def _buffer_sums(sd):
+    return np.array([[v.double().sum().item(), v.double().abs().sum().item()] for k, v in sd.items()
+                     if k.endswith('running_mean') or k.endswith('running_var')])
+
+
+def _check_against_fixture(g, gsum, gabs, losses, stats, rank0_bufs):
     rel = np.abs(gabs - g['grad_abs_sums']) / np.maximum(g['grad_abs_sums'], 1e-3 * g['grad_abs_sums'].max())
     assert rel.max() < 2e-3, f'sum|grad| deviates by {rel.max():.2e}'
     assert np.abs(gsum - g['grad_sums']).max() <= 2e-3 * g['grad_abs_sums'].max()
     assert np.abs(np.array(losses) - g['losses']).max() <= 1e-5
     if stats is not None:
         assert np.array_equal(stats, g['stats'])
-    if rank0_sd is not None:
-        got = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for k, v in rank0_sd.items()
-                        if k.endswith('running_mean') or k.endswith('running_var')])
-        assert np.abs(got - g['rank0_buffer_sums']).max() <= 1e-4 * max(1.0, np.abs(g['rank0_buffer_sums']).max())
+    if rank0_bufs is not None:
+        assert np.abs(rank0_bufs - g['rank0_buffer_sums']).max() <= 1e-4 * max(1.0, np.abs(g['rank0_buffer_sums']).max())
 
 
 @pytest.mark.parametrize('name', ['ddp_unet_resnet18_w2', 'ddp_linknet_resnet50_w4'])
@@ -62,7 +67,8 @@ def test_engine_reproduces_ddp_sharded_fixtures(cuda, name):
     net._grad_arena.copy_(acc)
     net.arena.grad = net._grad_arena
     grads = {k: v.cpu() for k, v in net.named_grads().items()}
-    _check_against_fixture(g, [n for n, _ in ref.named_parameters()], grads, losses, np.concatenate(stats, axis=0), rank0_sd)
+    gsum, gabs = _grad_sums([n for n, _ in ref.named_parameters()], grads)
+    _check_against_fixture(g, gsum, gabs, losses, np.concatenate(stats, axis=0), _buffer_sums(rank0_sd))
 
 
 def _free_port():
@@ -99,15 +105,22 @@ def _rank_main(rank, world, port, q):
         loss, logits, st = net.train_step_raw(img[lo:hi].to(dev), mask[lo:hi].to(dev), normalize=True, mean=MEAN, std=STD,
                                               grad_scale=1.0 / world, exchange=ex)
         torch.cuda.synchronize()
-        grads = {k: v.cpu() for k, v in net.named_grads().items()}
-        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        names = [n for n, _ in build(arch, enc, classes, seed).named_parameters()]
+        gsum, gabs = _grad_sums(names, {k: v.cpu() for k, v in net.named_grads().items()})
+        bufs = _buffer_sums({k: v.cpu() for k, v in net.state_dict().items()})
+        garena = net._grad_arena.cpu()
+        g0 = garena.clone()
+        dist.broadcast(g0, 0)
+        same_grads = bool(torch.equal(garena, g0))       # after the exchange EVERY rank holds the same averaged gradients
         opt = FusedOptimizer(net, 'Adam', 1e-3, 1e-4)
         opt.step()
         torch.cuda.synchronize()
         arena = net.arena.data.cpu()
         other = arena.clone()
         dist.broadcast(other, 0)
-        q.put((rank, loss.item(), st.cpu().numpy(), grads, sd if rank == 0 else None, list(ex.fired), bool(torch.equal(arena, other))))
+        # plain numpy / python objects only: torch tensors travel through a queue as file descriptors that die with this process
+        q.put((rank, float(loss.item()), st.cpu().numpy(), gsum, gabs, bufs, list(ex.fired), same_grads, bool(torch.equal(arena, other))))
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
@@ -124,21 +137,28 @@ def test_two_ranks_one_gpu_real_process_group(cuda):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
+    import time
     res = {}
-    for _ in range(world):
-        item = q.get()
-        res[item[0]] = item
+    t0 = time.time()
+    while len(res) < world:
+        if not q.empty():
+            item = q.get()
+            res[item[0]] = item
+            continue
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        assert not dead, f'a rank died with exit code {dead}'
+        assert time.time() - t0 < 400, 'ranks did not report'
+        time.sleep(0.2)
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    names = [n for n, _ in build(arch, enc, classes, seed).named_parameters()]
     losses = [res[r][1] for r in range(world)]
     stats = np.concatenate([res[r][2] for r in range(world)], axis=0)
     for r in range(world):   # after the exchange EVERY rank holds the averaged gradients
-        _check_against_fixture(g, names, res[r][3], losses, stats, res[0][4] if r == 0 else None)
-        fired = res[r][5]
+        _check_against_fixture(g, res[r][3], res[r][4], losses, stats, res[r][5] if r == 0 else None)
+        fired = res[r][6]
         assert len(fired) == 3 and sorted(k for k, _, _ in fired) == [0, 1, 2]
         assert fired[0][0] == 2, f'the highest arena range (decoder / head) must complete first, got {fired}'
-        assert res[r][6], 'parameters diverged between the ranks after the optimizer step'
-    for n in names:
-        assert torch.equal(res[0][3][n], res[1][3][n]), n
+        assert res[r][7], 'gradients differ between the ranks after the exchange'
+        assert res[r][8], 'parameters diverged between the ranks after the optimizer step'
+    _ = build
