@@ -7,9 +7,10 @@ forward (normalise + encoder-decoder) + Dice loss + backward + gradient all-redu
 
 Workload (BASELINE.json configs[1]): U-Net++ / resnet101, 1 class (Lumen), 704x704, bf16
 storage + bf16 MFMA inputs with f32 accumulate, batch 16 per GPU.  N > 1: one process per GPU
-(torchrun), data parallel with per-rank BN statistics / per-rank Dice and one RCCL all-reduce of
-the flat gradient arena (Lightning-DDP semantics, reference src/models/smp/train.py:122-133);
-per-GPU batch stays 16, so scaling is "weak".
+(torchrun), data parallel with per-rank BN statistics / per-rank Dice and the RCCL all-reduce of
+the flat gradient arena issued in slices beside the backward (Lightning-DDP semantics, reference
+src/models/smp/train.py:122-133); per-GPU batch stays 16, so scaling is "weak" (`--scaling strong`
+keeps the global batch at 16 instead: 16/N frames per GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline      -- the MFMA conv kernels (conv_mfma_kernel + wgrad_mfma_kernel), timed live with HIP
@@ -17,8 +18,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                    section 8d) / summed kernel time, vs 2.5 PFLOP/s dense bf16.  `achieved` comes from an
                    untimed extra pass with every launch on one stream (kernels alone); the brackets of the
                    timed, stream-overlapped steps are reported beside it under `overlapped`
-  cpu_baseline  -- the torch-CPU oracle (a port, not the reference's own files) on one 704x704
-                   frame of the same workload, fp32, all host cores
+  cpu_baseline  -- the torch-CPU oracle (a port, not the reference's own files) on the same workload at 704x704,
+                   2 frames per step, 1 warm-up + 3 timed steps, median; fp32 (`value`) and bf16 autocast
 """
 import argparse
 import json
@@ -41,39 +42,51 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(arch, enc, classes, size, seconds_hint=30.0):
-    """Oracle fwd + Dice + bwd + Adam on the host cores; bounded sample: ONE frame, fp32."""
+def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
+    """The CPU path beside the GPU number: the oracle's fwd + Dice + bwd + Adam
+    step on the host cores at the benchmark's full frame size, batch 2 (frames/s is per frame; 16 frames of U-Net++/r101
+    do not fit a sensible CPU budget), 1 warm-up + `timed` timed steps, median -- in fp32 (what the reference computes in)
+    and under torch's bf16 autocast.  Bounded sample: ~8 steps of 2 frames."""
     from oracle import create_model, DiceLoss
     from synth import make_batch
-    # the GPU box gives one-GPU jobs a 16-core share; os.cpu_count() reports the whole host
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))     # the share of the host this job may use, not os.cpu_count()
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    m = create_model(arch, enc, classes=classes).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
     loss_fn = DiceLoss()
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img, mask = make_batch(batch, classes, size, seed=2)
 
-    def step(img, mask):
-        opt.zero_grad()
-        loss = loss_fn(m((img - mean) / std), mask)
-        loss.backward()
-        opt.step()
+    def run(autocast):
+        torch.manual_seed(0)
+        m = create_model(arch, enc, classes=classes).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+        times = []
+        for i in range(1 + timed):
+            t0 = time.time()
+            opt.zero_grad()
+            if autocast:
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    z = m((img - mean) / std)
+                loss = loss_fn(z.float(), mask)
+            else:
+                loss = loss_fn(m((img - mean) / std), mask)
+            loss.backward()
+            opt.step()
+            if i > 0:
+                times.append(time.time() - t0)
+        times.sort()
+        return times[len(times) // 2], times
 
-    wi, wm = make_batch(1, classes, 64, seed=1)
-    step(wi, wm)  # warm the allocator / oneDNN primitives on a tiny frame
-    img, mask = make_batch(1, classes, size, seed=2)
-    t0 = time.time()
-    step(img, mask)
-    dt = time.time() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 step of 1 frame {size}x{size} fp32 ({arch}/{enc}, fwd+Dice+bwd+Adam), torch {torch.__version__} CPU oracle, '
-                      f'{dt:.1f} s'}
+    med32, t32 = run(False)
+    med16, t16 = run(True)
+    return {'value': round(batch / med32, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'bf16_autocast_value': round(batch / med16, 5),
+            'sample': f'median of {timed} timed steps after 1 warm-up, {batch} frames {size}x{size} per step ({arch}/{enc}, fwd+Dice+bwd+Adam), '
+                      f'torch {torch.__version__} CPU oracle on {cores} threads: fp32 {[round(t, 2) for t in t32]} s, '
+                      f'bf16 autocast {[round(t, 2) for t in t16]} s'}
 
 
 def main():
@@ -82,7 +95,10 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='unetpp_r101_704', choices=sorted(WORKLOADS))
-    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
+    ap.add_argument('--batch', type=int, default=16, help='frames per GPU (weak scaling) / frames in the global batch (strong scaling)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: --batch frames per GPU whatever N; strong: the global batch stays --batch, every GPU gets batch/N frames')
+    ap.add_argument('--allreduce-slices', type=int, default=3, help='gradient-arena slices all-reduced beside the backward (N > 1)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -110,20 +126,28 @@ def main():
 
     from oct_segmentation_amd import _lib as L
     from oct_segmentation_amd.model import OCTSegmentationModel
-    from oct_segmentation_amd.parallel import allreduce_gradients, broadcast_buffers, broadcast_parameters
+    from oct_segmentation_amd.parallel import GradientExchange, broadcast_buffers, broadcast_parameters, shard_range
     from synth import make_batch
     import ctypes as C
 
     arch, enc, classes, S = WORKLOADS[args.workload]
     B = args.batch
+    if args.scaling == 'strong':   # fixed global batch, sharded like the data-parallel loader does
+        lo, hi = shard_range(args.batch, rank, world)
+        B = hi - lo
+        if B < 1:
+            raise SystemExit(f'--scaling strong: global batch {args.batch} leaves rank {rank} of {world} without a frame')
+    global_batch = args.batch if args.scaling == 'strong' else world * B
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     names = ['Lumen', 'Fibrous cap', 'Lipid core', 'Vasa vasorum'][:classes]
     model = OCTSegmentationModel(arch, enc, 'bench', 3, names, lr=1e-5, weight_decay=0.0, optimizer_name=args.optimizer,
                                  input_size=S, device=dev, compute_dtype=cdt, seed=1234)
     model.train()
     net = model.model
+    exchange = None
     if world > 1:
         broadcast_parameters(net)
+        exchange = GradientExchange(net, nslices=args.allreduce_slices)
     opt = model.configure_optimizers()
     img, mask = make_batch(B, classes, S, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)
@@ -131,11 +155,9 @@ def main():
     def step():
         if world > 1:
             broadcast_buffers(net)  # torch-DDP broadcast_buffers=True
-        # grad_scale 1/world + SUM all-reduce == DDP's gradient mean
+        # grad_scale 1/world + SUM all-reduce == DDP's gradient mean; the all-reduce runs slice by slice beside the backward
         loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
-                                                 grad_scale=1.0 / world)
-        if world > 1:
-            allreduce_gradients(net, world, average=False)
+                                                 grad_scale=1.0 / world, exchange=exchange)
         opt.step()
         return loss
 
@@ -182,7 +204,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        frames = world * B * args.steps
+        frames = global_batch * args.steps
         macs = net.fwd_macs(B, S, S) / B  # per frame
         oms = [prof[0], prof[3], prof[6]]          # overlapped (timed) steps
         ofl = [prof[1], prof[4], prof[7]]
@@ -201,12 +223,12 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic OCT-shaped frames (seeded), random-init weights',
             'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+Dice+bwd+allreduce+{args.optimizer}',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
+                       'global_batch': global_batch, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
             'loss': round(loss_val, 6),
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
@@ -219,10 +241,10 @@ def main():
                 'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
                 'note': 'HIP-event brackets on the launch stream over an untimed pass of the same step with every launch on one '
                         'stream (octseg_debug_set_serial): the duration of each kernel alone; rocprofv3 summary of that mode: '
-                        'profiles/r1_serial_kernel_stats.csv',
+                        'profiles/r2_serial_kernel_stats.csv',
                 'overlapped': {
                     'note': 'the same brackets during the TIMED steps, where weight gradients and part of the decoder run on a '
-                            'side stream: durations include the time a kernel shares the chip (profiles/r1_w_bench_kernel_stats.csv)',
+                            'side stream: durations include the time a kernel shares the chip (profiles/r2_bench_kernel_stats.csv)',
                     'kernel_ms_per_step': round(sum(oms) / args.steps, 3),
                     'achieved': round(sum(ofl) / (sum(oms) * 1e-3) / 1e12, 2) if sum(oms) > 0 else 0.0,
                     'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
@@ -231,11 +253,13 @@ def main():
             },
         }
         # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)
-        tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
         if os.path.exists(tpath) and args.workload == 'unetpp_r101_704' and B == 16 and args.dtype == 'bf16':
             try:
                 out['roofline']['traffic'] = round(json.load(open(tpath))['mfma_family']['hbm_bytes_per_launch'])
-                out['roofline']['traffic_unit'] = 'HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_traffic.json)'
+                out['roofline']['traffic_unit'] = f'HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE, profiles/{os.path.basename(tpath)})'
             except Exception:
                 pass
         # the HBM-bound part of the step (SURVEY.md section 8d asks for both roofs): BatchNorm sweeps, kernels alone
@@ -249,7 +273,7 @@ def main():
                 'note': 'algorithmic bytes = every tensor these sweeps read or write, once; same untimed single-stream pass as roofline'}
         note(f'GPU: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; MFMA kernels {ach:.1f} TFLOP/s')
         if not args.no_cpu_baseline and world == 1:
-            note('CPU baseline (oracle, 1 frame) ...')
+            note('CPU baseline (oracle, 2 frames per step, fp32 + bf16 autocast) ...')
             out['cpu_baseline'] = cpu_baseline(arch, enc, classes, S)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -62,19 +62,19 @@ CSV_FIELDS = ['Epoch', 'Loss', 'IoU', 'Dice', 'Precision', 'Recall', 'F1', 'Spli
 
 
 def save_metrics_on_epoch(metrics_epoch, split, model_dir, classes, epoch, best_metrics=None):
-    """Epoch bookkeeping of the reference without W&B (``src/models/smp/utils.py:39-158``): aggregate the epoch's batch
+    """Epoch bookkeeping of the reference without W&B (``src/models/smp/utils.py:39-166``): aggregate the epoch's batch
     dicts with the pairwise running mean, append one row per class plus a ``Mean`` row to ``<model_dir>/metrics.csv``
     (header on first use, same column names), keep the best IoU / Dice / Precision / Recall with their epochs.
-    Returns ``(summary_dict, best_metrics)``; the summary carries the ``<split>/<metric>`` keys the reference logs."""
+    Values stay what the reference's arithmetic makes them (numpy float32 scalars written with ``str()``), so the file equals
+    the reference's byte for byte on the same batch dicts (tests/golden/reference_metrics.json).
+    Returns ``(summary_dict, best_metrics)``; the summary carries the ``<split>/<metric>`` keys the reference logs to W&B."""
     import csv
     import os
     m = aggregate_epoch(metrics_epoch)
-    per_class = {k: np.atleast_1d(np.asarray(m[k], dtype=np.float64)) for k in ('iou', 'dice', 'precision', 'recall', 'f1')}
-    summary = {f'{split}/loss': float(np.squeeze(m['loss']))}
-    for k, v in per_class.items():
-        summary[f'{split}/{k}'] = float(v.mean())
-        for i, cl in enumerate(classes):
-            summary[f'{split}/{k} ({cl})'] = float(v[i] if v.size > 1 else v[0])
+    names = ('iou', 'dice', 'precision', 'recall', 'f1')
+    summary = {f'{split}/loss': m['loss']}
+    for k in ('iou', 'dice', 'precision', 'recall', 'f1'):
+        summary[f'{split}/{k}'] = m[k].mean()
     if best_metrics is not None:
         for k in ('iou', 'dice', 'precision', 'recall'):
             cur = summary[f'{split}/{k}']
@@ -83,16 +83,17 @@ def save_metrics_on_epoch(metrics_epoch, split, model_dir, classes, epoch, best_
     os.makedirs(model_dir, exist_ok=True)
     path = os.path.join(model_dir, 'metrics.csv')
     new_file = not os.path.exists(path)
+    multi = len(classes) > 1
     with open(path, 'a', newline='') as f:
         w = csv.DictWriter(f, fieldnames=CSV_FIELDS)
         if new_file:
             w.writeheader()
         for i, cl in enumerate(classes):
-            pick = (lambda v: float(v[i] if v.size > 1 else v[0]))
-            w.writerow({'Epoch': epoch, 'Loss': summary[f'{split}/loss'], 'IoU': pick(per_class['iou']), 'Dice': pick(per_class['dice']),
-                        'Precision': pick(per_class['precision']), 'Recall': pick(per_class['recall']), 'F1': pick(per_class['f1']),
-                        'Split': split, 'Class': cl})
-        w.writerow({'Epoch': epoch, 'Loss': summary[f'{split}/loss'], 'IoU': summary[f'{split}/iou'], 'Dice': summary[f'{split}/dice'],
-                    'Precision': summary[f'{split}/precision'], 'Recall': summary[f'{split}/recall'], 'F1': summary[f'{split}/f1'],
-                    'Split': split, 'Class': 'Mean'})
+            pick = (lambda v: v[i] if multi else v)      # one class: the whole (length-1) array, as the reference writes it
+            for k in names:
+                summary[f'{split}/{k} ({cl})'] = pick(m[k])
+            w.writerow({'Epoch': epoch, 'Loss': m['loss'], 'IoU': pick(m['iou']), 'Dice': pick(m['dice']), 'Precision': pick(m['precision']),
+                        'Recall': pick(m['recall']), 'F1': pick(m['f1']), 'Split': split, 'Class': cl})
+        w.writerow({'Epoch': epoch, 'Loss': m['loss'], 'IoU': m['iou'].mean(), 'Dice': m['dice'].mean(), 'Precision': m['precision'].mean(),
+                    'Recall': m['recall'].mean(), 'F1': m['f1'].mean(), 'Split': split, 'Class': 'Mean'})
     return summary, best_metrics

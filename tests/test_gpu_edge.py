@@ -152,3 +152,81 @@ def test_fit_loop_with_gpu_augmentation(cuda, tmp_path):
     assert len(hist) == 2 and np.isfinite(float(hist[1]['train']['loss'])) and 0.0 <= float(hist[1]['train']['loss']) <= 1.0
     from oct_segmentation_amd import augment as A
     assert np.array_equal(A.sample_params(4, 64, np.random.default_rng(3)), A.sample_params(4, 64, np.random.default_rng(3)))
+
+
+def test_dice_gradient_of_saturated_logits(cuda):
+    """Regression of round 1's fuzz case k=19 (cosine 0.99899): with |logits| > 17 the sigmoid rounds to 1 in fp32 and dp/dz
+    written as p * (1 - p) vanished for every confidently-positive pixel, while autograd of logsigmoid(z).exp() keeps
+    exp(-z).  A head scaled x40 saturates the net; every gradient must still match the oracle."""
+    from oracle import DiceLoss
+    from test_gpu_net import _grad_report
+    ref, net = _pair('unet', 'resnet18', 1, cuda)
+    with torch.no_grad():
+        ref.segmentation_head[0].weight.mul_(40.0)
+    net.load_state_dict(ref.state_dict())
+    img, mask = make_batch(3, 1, 64, seed=19)
+    ref.train(); net.train()
+    z = ref(img)
+    assert float((z > 17).float().mean()) > 0.02 and float((z < -17).float().mean()) > 0.02, 'the case must saturate both ways'
+    DiceLoss()(z, mask).backward()
+    loss, logits, _ = net.train_step_raw(img.to(cuda), mask.to(cuda))
+    torch.cuda.synchronize()
+    cos, worst, name = _grad_report(net.named_grads(), ref)
+    print(f'saturated head: |z| max {z.abs().max().item():.1f}, grad cosine {cos:.8f}, worst {worst:.2e} ({name})')
+    assert cos > 0.999999 and worst < 5e-3
+
+
+def test_backward_of_a_stale_step_raises(cuda):
+    """One workspace per (B, H, W) plan holds the activations saved for backward: another forward of that shape between
+    training_step and loss.backward() overwrites them.  The reference (autograd keeps every graph alive) would still give the right
+    gradient; the engine cannot, so it must refuse instead of returning a wrong one."""
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    m = OCTSegmentationModel('unet', 'resnet18', 'x', 3, ['Lumen'], device=cuda, compute_dtype=torch.float32, seed=2).train()
+    img, mask = (t.to(cuda) for t in make_batch(2, 1, 64, seed=3))
+    out = m.training_step((img, mask), 0)
+    with torch.no_grad():
+        m.eval(); m(img); m.train()                   # e.g. a validation forward of the same shape
+    with pytest.raises(RuntimeError, match='stale step'):
+        out['loss'].backward()
+    out = m.training_step((img, mask), 0)             # the ordinary order still works
+    out['loss'].backward()
+    assert m.model.arena.grad is not None and torch.isfinite(m.model.arena.grad).all()
+    # a forward of ANOTHER shape does not touch this plan
+    out = m.training_step((img, mask), 0)
+    with torch.no_grad():
+        m.eval(); m(img[:1]); m.train()
+    out['loss'].backward()
+
+
+def test_encoder_weights_and_smp_kwargs(cuda, tmp_path):
+    """smp.create_model's encoder_weights (reference default 'imagenet', model.py:38-44): a torchvision ResNet state_dict / file is
+    loaded into encoder.*; 'imagenet' without a local file raises instead of silently training from scratch; unknown or
+    non-default smp keywords are rejected instead of dropped."""
+    from oct_segmentation_amd.engine import SegNet, create_model
+    from oracle import create_model as oracle_model
+    torch.manual_seed(3)
+    enc = oracle_model('unet', 'resnet18', classes=1).encoder
+    tv = {k: v.clone() for k, v in enc.state_dict().items()}
+    tv['fc.weight'] = torch.zeros(1000, 512); tv['fc.bias'] = torch.zeros(1000)     # torchvision files carry the classifier too
+    path = os.path.join(tmp_path, 'resnet18.pth')
+    torch.save(tv, path)
+    for src in (tv, path):
+        net = SegNet('linknet', 'resnet18', encoder_weights=src, classes=2, device=cuda, compute_dtype=torch.float32, seed=9)
+        sd = net.state_dict()
+        for k, v in enc.state_dict().items():
+            assert torch.equal(sd['encoder.' + k].cpu(), v), k
+    with pytest.raises(RuntimeError, match='no pretrained weights can be downloaded'):
+        SegNet('unet', 'resnet18', encoder_weights='imagenet', device=cuda)
+    os.environ['OCTSEG_IMAGENET_DIR'] = str(tmp_path)
+    try:
+        net = create_model('unet', 'resnet18', encoder_weights='imagenet', classes=1, device=cuda, compute_dtype=torch.float32)
+        assert torch.equal(net.state_dict()['encoder.conv1.weight'].cpu(), tv['conv1.weight'])
+    finally:
+        del os.environ['OCTSEG_IMAGENET_DIR']
+    with pytest.raises(RuntimeError, match='do not fit'):
+        SegNet('unet', 'resnet34', encoder_weights=tv, device=cuda)
+    with pytest.raises(NotImplementedError):
+        SegNet('unet', 'resnet18', device=cuda, decoder_attention_type='scse')
+    with pytest.raises(TypeError):
+        SegNet('unet', 'resnet18', device=cuda, not_an_smp_option=1)
+    SegNet('unet', 'resnet18', device=cuda, decoder_use_batchnorm=True, encoder_depth=5, decoder_channels=[256, 128, 64, 32, 16])
