@@ -42,6 +42,37 @@ WORKLOADS = {
 }
 
 
+def host_cores():
+    """CPU threads this job may really use: the affinity mask, cut down to the cgroup CPU quota when there is one.  A one-GPU job
+    on the GPU boxes sees every core of the host in its affinity mask but is scheduled on a 16-core share; running oneDNN with
+    one thread per visible core then oversubscribes the share by an order of magnitude (a 704x704 step did not finish in 7
+    minutes), hence the cap of 16 when the mask is large and no quota can be read."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = 'sched_getaffinity'
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:              # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()
+            if q != 'max':
+                quota = max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:   # cgroup v1
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, q // p)
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, how = quota, 'cgroup cpu quota'
+    elif n > 32:
+        n, how = 16, f'capped: affinity mask shows {n} cores, the one-GPU share of a box is 16'
+    return n, how
+
+
 def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
     """The CPU path beside the GPU number: the oracle's fwd + Dice + bwd + Adam
     step on the host cores at the benchmark's full frame size, batch 2 (frames/s is per frame; 16 frames of U-Net++/r101
@@ -49,21 +80,21 @@ def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
     and under torch's bf16 autocast.  Bounded sample: ~8 steps of 2 frames."""
     from oracle import create_model, DiceLoss
     from synth import make_batch
-    try:
-        cores = len(os.sched_getaffinity(0))     # the share of the host this job may use, not os.cpu_count()
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, how = host_cores()
+    print(f'[bench] cpu baseline on {cores} threads ({how})', file=sys.stderr, flush=True)
     torch.set_num_threads(cores)
     loss_fn = DiceLoss()
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     img, mask = make_batch(batch, classes, size, seed=2)
 
-    def run(autocast):
+    def run(autocast, budget_s):
+        """1 warm-up + `timed` steps; stops early (and says so) when the leg exceeds its time budget -- bf16 convolutions have no fast
+        path on every host CPU, and the default bench run has to finish within minutes."""
         torch.manual_seed(0)
         m = create_model(arch, enc, classes=classes).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-5)
-        times = []
+        times, t_leg = [], time.time()
         for i in range(1 + timed):
             t0 = time.time()
             opt.zero_grad()
@@ -75,18 +106,20 @@ def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
                 loss = loss_fn(m((img - mean) / std), mask)
             loss.backward()
             opt.step()
-            if i > 0:
-                times.append(time.time() - t0)
-        times.sort()
-        return times[len(times) // 2], times
+            times.append(time.time() - t0)
+            print(f'[bench] cpu {"bf16-autocast" if autocast else "fp32"} step {i}: {times[-1]:.1f} s', file=sys.stderr, flush=True)
+            if time.time() - t_leg + times[-1] > budget_s and i < timed:
+                break
+        kept = sorted(times[1:]) if len(times) > 1 else times     # the warm-up step only counts when it is all there is
+        return kept[len(kept) // 2], times
 
-    med32, t32 = run(False)
-    med16, t16 = run(True)
+    med32, t32 = run(False, 120.0)
+    med16, t16 = run(True, 60.0)
     return {'value': round(batch / med32, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'bf16_autocast_value': round(batch / med16, 5),
-            'sample': f'median of {timed} timed steps after 1 warm-up, {batch} frames {size}x{size} per step ({arch}/{enc}, fwd+Dice+bwd+Adam), '
-                      f'torch {torch.__version__} CPU oracle on {cores} threads: fp32 {[round(t, 2) for t in t32]} s, '
-                      f'bf16 autocast {[round(t, 2) for t in t16]} s'}
+            'sample': f'{batch} frames {size}x{size} per step ({arch}/{enc}, fwd+Dice+bwd+Adam), torch {torch.__version__} CPU oracle on {cores} '
+                      f'threads; step times incl. the warm-up step 0 (median of the rest, or the warm-up alone if the leg ran out of its '
+                      f'time budget): fp32 {[round(t, 2) for t in t32]} s, bf16 autocast {[round(t, 2) for t in t16]} s'}
 
 
 def main():

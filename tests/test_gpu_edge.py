@@ -161,13 +161,18 @@ def test_dice_gradient_of_saturated_logits(cuda):
     from oracle import DiceLoss
     from test_gpu_net import _grad_report
     ref, net = _pair('unet', 'resnet18', 1, cuda)
-    with torch.no_grad():
-        ref.segmentation_head[0].weight.mul_(40.0)
-    net.load_state_dict(ref.state_dict())
     img, mask = make_batch(3, 1, 64, seed=19)
     ref.train(); net.train()
+    with torch.no_grad():
+        z0 = ref(img)
+        lo, hi = z0.quantile(0.2), z0.quantile(0.8)       # logits of both signs: the 20 % / 80 % quantiles land on -25 / +25
+        k = 50.0 / (hi - lo)
+        ref.segmentation_head[0].bias.sub_((hi + lo) / 2)
+        ref.segmentation_head[0].weight.mul_(k)
+        ref.segmentation_head[0].bias.mul_(k)
+    net.load_state_dict(ref.state_dict())
     z = ref(img)
-    assert float((z > 17).float().mean()) > 0.02 and float((z < -17).float().mean()) > 0.02, 'the case must saturate both ways'
+    assert float((z > 17).float().mean()) > 0.1 and float((z < -17).float().mean()) > 0.1, 'the case must saturate both ways'
     DiceLoss()(z, mask).backward()
     loss, logits, _ = net.train_step_raw(img.to(cuda), mask.to(cuda))
     torch.cuda.synchronize()
