@@ -79,6 +79,14 @@ template <> struct Tr<bf16_t> {
   static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo) {
     return affine_floor(v, sc, sh, lo == 0.f ? 0u : 0x80008000u);
   }
+  static __device__ __forceinline__ void unpack8(const uint4& v, float* x) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = __uint_as_float(w[i] << 16); x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ uint4 pack8(const float* x) {
+    return make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
+  }
   static __device__ __forceinline__ float load(const void* p, size_t i) {
     return __uint_as_float((unsigned)((const bf16_t*)p)[i] << 16);
   }

@@ -54,6 +54,12 @@ template <> struct RowMap<true> {
   }
 };
 
+#ifdef OCTSEG_PLAIN_ROWMAP
+constexpr bool ROWMAP_GROUPED = false;   // A/B build switch
+#else
+constexpr bool ROWMAP_GROUPED = true;
+#endif
+
 struct TilePos { int n, y0, x0, co0, w_mt, nt_idx; };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
@@ -114,13 +120,19 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
   float* red = (float*)(smem + BM * OPITCH);             // [WM][BN][2] stat partials
   const bool head = a.out_mode == OUT_HEAD_NCHW;
   float s1[NT], s2[NT];
-  if constexpr (!GROUPED) {
+  {
     // Fast path (block-uniform): tile fully inside the output, one destination.  Everything below is the same
     // arithmetic in the same order as the general path, minus the per-element bounds checks, the destination
     // search and the per-vector 64-bit address math (the general path is ~4000 instructions per thread).
     if (!head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
       constexpr int ES = (int)sizeof(T);
-      const int lbase = (wm * 4 * TW + 4 * h) * OPITCH + (wn * NT * 32 + r) * ES;
+      // accumulator element i of lane (r, h) is A row rr = (i & 3) + 8 * (i >> 2) + 4 * h; its pixel inside the wave's strip:
+      //   plain row map:   row (i >> 3), column (i & 3) + 8 * ((i >> 2) & 1) + 4 * h
+      //   grouped row map: row h ^ [(i >> 2) is 1 or 2], column 4 * (i >> 2) + (i & 3)      (RowMap<true>)
+      const int lchan = (wn * NT * 32 + r) * ES;
+      const int lbase = GROUPED ? (wm * 4 * TW + h * TW) * OPITCH + lchan : (wm * 4 * TW + 4 * h) * OPITCH + lchan;
+      const int lbase_x = (wm * 4 * TW + (1 - h) * TW) * OPITCH + lchan;   // grouped: the other row of the strip
+      (void)lbase_x;
       // transposed tile into LDS; the bias add and the BN partial sums only where the layer has them (uniform
       // branches: a dgrad has neither and saves three of its four vector instructions per element)
       auto emit = [&](auto bias_c, auto stat_c) __attribute__((always_inline)) {
@@ -140,9 +152,16 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
               float val = acc[mt][nt][i];
               if constexpr (HAS_BIAS) val += bias;
               if constexpr (HAS_STAT) { s1[nt] += val; s2[nt] += val * val; }
-              const int off = ((mt * 2 + (i >> 3)) * TW + (i & 3) + 8 * ((i >> 2) & 1)) * OPITCH + nt * 32 * ES;
-              if (sizeof(T) == 4) *(float*)(otile + lbase + off) = val;
-              else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lbase + off) = __builtin_bit_cast(unsigned short, b); }
+              int off, lb;
+              if constexpr (GROUPED) {
+                off = (mt * 2 * TW + 4 * (i >> 2) + (i & 3)) * OPITCH + nt * 32 * ES;
+                lb = ((0x6 >> (i >> 2)) & 1) ? lbase_x : lbase;
+              } else {
+                off = ((mt * 2 + (i >> 3)) * TW + (i & 3) + 8 * ((i >> 2) & 1)) * OPITCH + nt * 32 * ES;
+                lb = lbase;
+              }
+              if (sizeof(T) == 4) *(float*)(otile + lb + off) = val;
+              else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lb + off) = __builtin_bit_cast(unsigned short, b); }
             }
           }
         }
@@ -446,7 +465,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   int abase[2], bbase[NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int ty = wm * 4 + mt * 2 + (r >> 4), tx = r & 15;
+    // grouped row map: the 16 lanes one ds_read_b128 LDS cycle serves read 16 CONSECUTIVE pixels of one window row, whose
+    // 144-byte pitch spreads them over all 16 sixteen-byte slots of the 256-byte LDS line for every tap shift and window
+    // width (the plain map mixed lanes of both strip rows in one group: two 2-way conflicts per group at RW = 18, 30 % of
+    // all LDS cycles of the 3x3 layers, profiles/r1_sq_counters_conv3x3_512_256_352.txt)
+    const int ty = wm * 4 + mt * 2 + RowMap<ROWMAP_GROUPED>::ty(r), tx = RowMap<ROWMAP_GROUPED>::tx(r);
     abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
   }
   int bswz[NT];  // XOR swizzle of the 16-byte chunk index inside a slab row (matches pack_weight_image)
@@ -920,7 +943,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
 #endif
 
-  conv_epilogue<T, NT, WN, WM, false>(a, smem, acc, tp);
+  conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED>(a, smem, acc, tp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1129,6 +1152,7 @@ static bool flatten_1x1(ConvArgs& a) {
 }
 
 int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
+  if (gemm1x1_eligible(a0, dtype)) return gemm1x1_rows(a0);
   ConvArgs a = a0;
   flatten_1x1(a);
   return conv_num_mtiles(a, dtype);
@@ -1136,6 +1160,7 @@ int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
 
 hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
   if (a0.ntaps <= 0) return hipSuccess;
+  if (gemm1x1_eligible(a0, dtype)) return launch_gemm1x1(dtype, a0, st);
   ConvArgs a = a0;
   flatten_1x1(a);
   {

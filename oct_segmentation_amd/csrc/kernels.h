@@ -16,6 +16,13 @@ static inline size_t conv_image_bytes(const ConvPackInfo& p, int wtaps) {
 }
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
 
+// gemm1x1.hip: stride-1, single-source 1x1 convs and their data gradients as a persistent GEMM (2-byte dtypes); consumes the same
+// packed weight image as conv_mfma_kernel.  launch_conv routes eligible launches there; its BN-stat slab has one row per
+// workgroup (gemm1x1_rows) instead of one per M tile.
+bool gemm1x1_eligible(const ConvArgs& a, int dtype);
+int gemm1x1_rows(const ConvArgs& a);
+hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t st);
+
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 

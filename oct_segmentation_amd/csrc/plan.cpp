@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -510,9 +511,16 @@ static int build_plan(octseg_plan* P) {
       int rows = 0;
       for (auto& a : la) {
         // geometry-only descriptors, so that the tile count equals what run_forward will launch
+        // (everything the kernel choice looks at: launch_conv routes stride-1 single-source 1x1 layers to gemm1x1.hip, whose
+        //  slab has one row per workgroup; run_forward checks that it lands on the same row count)
         a.nsrc = 0;
-        for (auto& s : L.srcs) { SrcDesc d{}; d.H = P->tensors[s.v.t].H; d.W = P->tensors[s.v.t].W; d.up = s.up; a.src[a.nsrc++] = d; }
-        DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; a.dst[0] = dd; a.ndst = 1;
+        int c0 = 0;
+        for (auto& s : L.srcs) {
+          SrcDesc d{}; d.H = P->tensors[s.v.t].H; d.W = P->tensors[s.v.t].W; d.up = s.up; d.C = P->tensors[s.v.t].C; d.c0 = c0;
+          c0 += d.C; a.src[a.nsrc++] = d;
+        }
+        DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; dd.C = L.Cout; dd.cn = L.Cout; a.dst[0] = dd; a.ndst = 1;
+        a.bias = L.b >= 0 ? (const float*)(uintptr_t)16 : nullptr;   // presence only
         a.out_mode = L.head ? OUT_HEAD_NCHW : OUT_STORE;
         rows += conv_num_mtiles_flat(a, P->dtype);
       }
@@ -725,6 +733,8 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           ProfScope ps(0, 2.0 * layer_macs(L) / (double)la.size(), st, L.name);
           HIPCHK(launch_conv(P->dtype, a, st));
         }
+        if (L.bn >= 0 && E.train && row0 != P->bns[L.bn].rows)
+          return fail(OCTSEG_BAD_ARG, "internal: BN-statistics slab rows of " + L.name + " differ between plan and launch");
         if (L.out >= 0) tseq[L.out] = stamp;
         break;
       }

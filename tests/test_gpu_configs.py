@@ -72,7 +72,7 @@ def _full_size_properties(cuda, arch, enc, classes, B, augment=False, S=704):
     assert abs(loss.item() - _dice_f64(logits, mask)) <= 2e-6      # fp32 sigmoid, f64 sums in the kernel
     assert 0.0 <= loss.item() <= 1.0
     nz = float((g1 != 0).float().mean())
-    assert nz > 0.9, f'only {nz:.2f} of the gradient arena is non-zero'
+    assert nz > 0.99, f'only {nz:.2f} of the gradient arena is non-zero'
     buf = net.bn_buffers.clone()
     net.bn_buffers.zero_()
     loss2, logits2, _ = net.train_step_raw(img, mask, normalize=True, mean=mean, std=std, grad_scale=0.5)
@@ -141,7 +141,10 @@ def test_c5_ensemble_704_graph_replay(cuda, tmp_path):
     _ = rng
 
 
-BF16_PARITY = [('unetplusplus', 'resnet50', 1, 2, 256), ('linknet', 'resnet50', 2, 2, 256), ('unetplusplus', 'resnet101', 1, 2, 256)]
+BF16_PARITY = [('unetplusplus', 'resnet50', 1, 2, 256), ('linknet', 'resnet50', 2, 2, 256), ('unetplusplus', 'resnet101', 1, 2, 256),
+               # 9 x 64 x 64 = 288 M tiles in layer1: the persistent 1x1 GEMM (gemm1x1.hip) walks several tiles per workgroup with
+               # its BatchNorm partial sums carried across them (conv3: two N tiles on 256 workgroup rows)
+               ('unet', 'resnet50', 1, 9, 256)]
 
 
 @pytest.mark.parametrize('cfg', BF16_PARITY, ids=['-'.join(map(str, c)) for c in BF16_PARITY])

@@ -23,6 +23,14 @@ CASES = [
     (2, 8, 16, 64, 64, 4, 2, 1, True),       # ConvTranspose2d k4 s2 p1
     (1, 12, 20, 16, 32, 4, 2, 1, True),
     (1, 16, 16, 160, 64, 1, 1, 0, False),    # stem GEMM shape (K = 160)
+    # stride-1 1x1 layers: the persistent GEMM kernel (gemm1x1.hip) in bf16 where K % 64 == 0, conv_mfma_kernel otherwise / in f32
+    (3, 7, 5, 128, 40, 1, 1, 0, False),      # ragged M tile (105 pixels), N tile of 64 with 40 real channels
+    (2, 12, 12, 256, 320, 1, 1, 0, False),   # three N tiles, the last one half full; dgrad contracts over 320 channels (5 K steps)
+    (1, 44, 44, 1024, 256, 1, 1, 0, False),  # ResNet-101 layer3 conv1: 16 M tiles, 16 K steps
+    (4, 22, 22, 256, 1024, 1, 1, 0, False),  # layer3 conv3: 8 N tiles
+    (2, 24, 24, 64, 16, 1, 1, 0, False),     # LinkNet decoder tail: one 32-wide N tile, one K step
+    (8, 96, 96, 64, 64, 1, 1, 0, False),     # 576 M tiles > 512 workgroups: some walk two tiles (pipeline across the tile boundary)
+    (5, 96, 96, 128, 256, 1, 1, 0, False),   # 360 M tiles x 2 N tiles on 256 workgroup rows, two K steps, ragged walk (104 rows do two tiles)
 ]
 
 
