@@ -53,7 +53,9 @@ typedef enum {
   OCTSEG_BAD_ARG = -5
 } octseg_status;
 
-typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1 } octseg_dtype;
+/* OCTSEG_F16: IEEE half storage + v_mfma_f32_32x32x16_f16, the serving dtype of the ensemble path (reference src/predict.py; BASELINE
+ * config #5).  Eval forwards only: octseg_net_forward(train = 1) and the backward entry points return OCTSEG_BAD_DTYPE for it. */
+typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
   const char* arch;     /* "unet" | "unetplusplus" | "linknet" (case-insensitive) */

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liboctseg_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 P_CONV, P_CONVT, P_STEM, P_VEC = 0, 1, 2, 3
 OPT_KINDS = {'SGD': 0, 'Adam': 1, 'RMSprop': 2, 'RAdam': 3}
 

@@ -6,8 +6,9 @@
 namespace octseg {
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM (same layout as torch.bfloat16)
+struct f16_t { unsigned short bits; };  // raw IEEE half bits (torch.float16): the serving dtype of BASELINE config #5 (eval forward only)
 
-enum DType { DT_F32 = 0, DT_BF16 = 1 };
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 constexpr int MAX_SRC = 5;    // U-Net++ dense concat: up + 3 dense + encoder feature
@@ -60,6 +61,7 @@ struct ConvArgs {
   int ostride, ooy, oox;  // output pixel = grid * ostride + (ooy, oox)
   int out_mode;
   const float* bias;      // per-Cout, nullable
+  int relu_out;           // eval with BatchNorm folded into the weight image: the epilogue stores relu(acc + bias)
   float* stat_slab;       // nullable: [slab rows][Cout][2] partial (sum, sumsq) per M tile
   int slab_row0;
   int src_uniform;        // set by launch_conv: every source starts on a K-chunk boundary (the per-chunk source choice is then scalar)

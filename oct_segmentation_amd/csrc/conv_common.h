@@ -38,6 +38,11 @@ template <> struct Tr<float> {
   }
   static __device__ __forceinline__ float load(const void* p, size_t i) { return ((const float*)p)[i]; }
   static __device__ __forceinline__ void store(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+  // 16-bit helpers of the 2-byte specialisations: present so that `if (sizeof(T) == 4) ... else ...` bodies compile; never executed
+  static __device__ __forceinline__ float lo(unsigned) { return 0.f; }
+  static __device__ __forceinline__ float hi(unsigned) { return 0.f; }
+  static __device__ __forceinline__ unsigned pk(float, float) { return 0u; }
+  static __device__ __forceinline__ unsigned short bits16(float) { return 0; }
 };
 static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   // one v_cvt_pk_bf16_f32 (two scalar conversions + shift + or took four instructions)
@@ -79,6 +84,11 @@ template <> struct Tr<bf16_t> {
   static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo) {
     return affine_floor(v, sc, sh, lo == 0.f ? 0u : 0x80008000u);
   }
+  // the two halves of a packed pair as f32, a pair from two f32 (round to nearest even), one value's 16 bits
+  static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ unsigned pk(float l, float h) { return pack_bf16(l, h); }
+  static __device__ __forceinline__ unsigned short bits16(float v) { __bf16 b = (__bf16)v; return __builtin_bit_cast(unsigned short, b); }
   static __device__ __forceinline__ void unpack8(const uint4& v, float* x) {
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -94,6 +104,52 @@ template <> struct Tr<bf16_t> {
     __bf16 b = (__bf16)v;
     ((bf16_t*)p)[i] = __builtin_bit_cast(unsigned short, b);
   }
+};
+
+// IEEE half storage (serving, BASELINE config #5): same kernels, v_mfma_f32_32x32x16_f16 (the bf16 form's rate), f32 accumulate.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <> struct Tr<f16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+  static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+  static __device__ __forceinline__ unsigned pk(float l, float h) {
+    const f16x2_t v = {(_Float16)l, (_Float16)h};   // v_cvt_f16_f32 rounds to nearest even (v_cvt_pkrtz would truncate)
+    return __builtin_bit_cast(unsigned, v);
+  }
+  static __device__ __forceinline__ unsigned short bits16(float v) { const _Float16 x = (_Float16)v; return __builtin_bit_cast(unsigned short, x); }
+  // relu?(x * scale + shift) on 8 channels; floor16 = 0: ReLU (v_pk_max_f16 on the rounded pair), anything else: none
+  static __device__ __forceinline__ uint4 affine_floor(uint4 v, const float* sc, const float* sh, unsigned floor16) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+    const f16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float l = fmaf(lo(w[i]), sc[2 * i], sh[2 * i]), h = fmaf(hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
+      f16x2_t p = {(_Float16)l, (_Float16)h};
+      if (floor16 == 0u) p = __builtin_elementwise_max(p, zero);
+      w[i] = __builtin_bit_cast(unsigned, p);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ uint4 affine(uint4 v, const float* sc, const float* sh, int relu) {
+    return affine_floor(v, sc, sh, relu ? 0u : 0x80008000u);
+  }
+  static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo_) {
+    return affine_floor(v, sc, sh, lo_ == 0.f ? 0u : 0x80008000u);
+  }
+  static __device__ __forceinline__ void unpack8(const uint4& v, float* x) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = lo(w[i]); x[2 * i + 1] = hi(w[i]); }
+  }
+  static __device__ __forceinline__ uint4 pack8(const float* x) { return make_uint4(pk(x[0], x[1]), pk(x[2], x[3]), pk(x[4], x[5]), pk(x[6], x[7])); }
+  static __device__ __forceinline__ float load(const void* p, size_t i) {
+    return (float)__builtin_bit_cast(_Float16, ((const unsigned short*)p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, size_t i, float v) { ((unsigned short*)p)[i] = bits16(v); }
 };
 
 // Per-thread view of the source its channel vector falls into (resolved once per chunk).

@@ -135,8 +135,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       (void)lbase_x;
       // transposed tile into LDS; the bias add and the BN partial sums only where the layer has them (uniform
       // branches: a dgrad has neither and saves three of its four vector instructions per element)
-      auto emit = [&](auto bias_c, auto stat_c) __attribute__((always_inline)) {
-        constexpr bool HAS_BIAS = decltype(bias_c)::value, HAS_STAT = decltype(stat_c)::value;
+      auto emit = [&](auto bias_c, auto stat_c, auto relu_c) __attribute__((always_inline)) {
+        constexpr bool HAS_BIAS = decltype(bias_c)::value, HAS_STAT = decltype(stat_c)::value, HAS_RELU = decltype(relu_c)::value;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           s1[nt] = 0.f; s2[nt] = 0.f;
@@ -151,6 +151,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             for (int i = 0; i < 16; ++i) {
               float val = acc[mt][nt][i];
               if constexpr (HAS_BIAS) val += bias;
+              if constexpr (HAS_RELU) val = fmaxf(val, 0.f);   // eval, BatchNorm folded: the activation is stored, not the raw conv output
               if constexpr (HAS_STAT) { s1[nt] += val; s2[nt] += val * val; }
               int off, lb;
               if constexpr (GROUPED) {
@@ -161,14 +162,15 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
                 lb = lbase;
               }
               if (sizeof(T) == 4) *(float*)(otile + lb + off) = val;
-              else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + lb + off) = __builtin_bit_cast(unsigned short, b); }
+              else *(unsigned short*)(otile + lb + off) = Tr<T>::bits16(val);
             }
           }
         }
       };
       using std::true_type; using std::false_type;
-      if (a.bias != nullptr) { if (a.stat_slab != nullptr) emit(true_type{}, true_type{}); else emit(true_type{}, false_type{}); }
-      else { if (a.stat_slab != nullptr) emit(false_type{}, true_type{}); else emit(false_type{}, false_type{}); }
+      if (a.relu_out) emit(true_type{}, false_type{}, true_type{});   // (host: relu_out comes with the folded bias, never with statistics)
+      else if (a.bias != nullptr) { if (a.stat_slab != nullptr) emit(true_type{}, true_type{}, false_type{}); else emit(true_type{}, false_type{}, false_type{}); }
+      else { if (a.stat_slab != nullptr) emit(false_type{}, true_type{}, false_type{}); else emit(false_type{}, false_type{}, false_type{}); }
       if (a.stat_slab != nullptr) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -225,10 +227,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
               for (int j = 0; j < 4; ++j) sacc += __uint_as_float(qq[j][i]);
               r4[i] = __float_as_uint(sacc);
             } else {
-              float lo = dacc ? __uint_as_float(o[i] << 16) : 0.f, hi = dacc ? __uint_as_float(o[i] & 0xffff0000u) : 0.f;
+              float lo = dacc ? Tr<T>::lo(o[i]) : 0.f, hi = dacc ? Tr<T>::hi(o[i]) : 0.f;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) { lo += __uint_as_float(qq[j][i] << 16); hi += __uint_as_float(qq[j][i] & 0xffff0000u); }
-              r4[i] = pack_bf16(lo, hi);
+              for (int j = 0; j < 4; ++j) { lo += Tr<T>::lo(qq[j][i]); hi += Tr<T>::hi(qq[j][i]); }
+              r4[i] = Tr<T>::pk(lo, hi);
             }
           }
           *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
@@ -260,9 +262,9 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             const unsigned ov[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float lo = __uint_as_float(nv[i] << 16) + __uint_as_float(ov[i] << 16);
-              const float hi = __uint_as_float(nv[i] & 0xffff0000u) + __uint_as_float(ov[i] & 0xffff0000u);
-              nv[i] = pack_bf16(lo, hi);
+              const float lo = Tr<T>::lo(nv[i]) + Tr<T>::lo(ov[i]);
+              const float hi = Tr<T>::hi(nv[i]) + Tr<T>::hi(ov[i]);
+              nv[i] = Tr<T>::pk(lo, hi);
             }
             val = make_uint4(nv[0], nv[1], nv[2], nv[3]);
           }
@@ -293,7 +295,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;   // A row of this accumulator element
         const int ty = wm * 4 + mt * 2 + RowMap<GROUPED>::ty(rr), tx = RowMap<GROUPED>::tx(rr);
         const int gy = y0 + ty, gx = x0 + tx;
-        const float val = acc[mt][nt][i] + bias;
+        float val = acc[mt][nt][i] + bias;
+        if (a.relu_out) val = fmaxf(val, 0.f);
         if (cok && gy < a.OH && gx < a.OW) {
           s1[nt] += val; s2[nt] += val * val;
           if (head) {
@@ -304,7 +307,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
         }
         if (!head) {
           if (sizeof(T) == 4) *(float*)(otile + (ty * TW + tx) * OPITCH + cl * 4) = val;
-          else { __bf16 b = (__bf16)val; *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = __builtin_bit_cast(unsigned short, b); }
+          else *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = Tr<T>::bits16(val);
         }
       }
     }
@@ -367,10 +370,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             for (int j = 0; j < 4; ++j) sacc += __uint_as_float(qq[j][i]);
             r4[i] = __float_as_uint(sacc);
           } else {
-            float lo = dacc ? __uint_as_float(o[i] << 16) : 0.f, hi = dacc ? __uint_as_float(o[i] & 0xffff0000u) : 0.f;
+            float lo = dacc ? Tr<T>::lo(o[i]) : 0.f, hi = dacc ? Tr<T>::hi(o[i]) : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { lo += __uint_as_float(qq[j][i] << 16); hi += __uint_as_float(qq[j][i] & 0xffff0000u); }
-            r4[i] = pack_bf16(lo, hi);
+            for (int j = 0; j < 4; ++j) { lo += Tr<T>::lo(qq[j][i]); hi += Tr<T>::hi(qq[j][i]); }
+            r4[i] = Tr<T>::pk(lo, hi);
           }
         }
         *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
@@ -391,9 +394,9 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
           const unsigned ov[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float lo = __uint_as_float(nv[i] << 16) + __uint_as_float(ov[i] << 16);
-            const float hi = __uint_as_float(nv[i] & 0xffff0000u) + __uint_as_float(ov[i] & 0xffff0000u);
-            nv[i] = pack_bf16(lo, hi);
+            const float lo = Tr<T>::lo(nv[i]) + Tr<T>::lo(ov[i]);
+            const float hi = Tr<T>::hi(nv[i]) + Tr<T>::hi(ov[i]);
+            nv[i] = Tr<T>::pk(lo, hi);
           }
           val = make_uint4(nv[0], nv[1], nv[2], nv[3]);
         }
@@ -1173,6 +1176,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
     a.tile_order = force >= 0 ? force : 1;
   }
   if (dtype == DT_F32) return dispatch<float>(a, st);
+  if (dtype == DT_F16) return dispatch<f16_t>(a, st);
   return dispatch<bf16_t>(a, st);
 }
 

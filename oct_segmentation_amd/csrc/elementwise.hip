@@ -37,6 +37,23 @@ template <> struct EV<bf16_t> {
     return make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
   }
 };
+template <> struct EV<f16_t> {   // IEEE half (serving dtype): conversions round to nearest even
+  static constexpr int VEC = 8;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* x) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const h2_t p = __builtin_bit_cast(h2_t, w[i]); x[2 * i] = (float)p[0]; x[2 * i + 1] = (float)p[1]; }
+  }
+  static __device__ __forceinline__ uint4 pack(const float* x) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const h2_t p = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]}; w[i] = __builtin_bit_cast(unsigned, p); }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+// f16 is the dtype of eval forwards only: the training-only sweeps have no f16 instantiation and refuse it
+#define OCTSEG_NO_F16(dtype) do { if ((dtype) == DT_F16) return hipErrorInvalidValue; } while (0)
 template <typename T> static __device__ __forceinline__ uint4 ldv(const void* p, size_t vec_idx) {
   return ((const uint4*)p)[vec_idx];
 }
@@ -171,7 +188,9 @@ __global__ __launch_bounds__(256) void bn_finalize_eval_all_kernel(const float* 
   const float sc = params[jb.gamma_off + c] / sqrtf(buffers[jb.rv_off + c] + eps);
   float* ss = (float*)(ws + jb.ss_off);
   ss[c] = sc;
-  ss[jb.C + c] = params[jb.beta_off + c] - buffers[jb.rm_off + c] * sc;
+  float sh = params[jb.beta_off + c] - buffers[jb.rm_off + c] * sc;
+  if (jb.bias_off != ~(size_t)0) sh = fmaf(params[jb.bias_off + c], sc, sh);   // (conv + b) * scale + shift: ConvTranspose2d of LinkNet
+  ss[jb.C + c] = sh;
 }
 hipError_t launch_bn_finalize_eval_all(const float* params, const float* buffers, void* ws, const BnEvalJob* tab, const unsigned* prefix,
                                        int njobs, unsigned total, float eps, hipStream_t st) {
@@ -197,8 +216,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
     const int c = (int)(v % vpc) * VEC;
     float x[VEC];
     EV<T>::unpack(ldv<T>(a.y, v), x);
+    if (a.scale) {   // (nullptr: BatchNorm already folded into the producing conv, eval)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) x[i] = fmaf(x[i], a.scale[c + i], a.shift[c + i]);
+      for (int i = 0; i < VEC; ++i) x[i] = fmaf(x[i], a.scale[c + i], a.shift[c + i]);
+    }
     if (a.res) {
       float rr[VEC];
       EV<T>::unpack(ldv<T>(a.res, v), rr);
@@ -235,7 +256,8 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
   const int vpc = a.C / (dtype == DT_F32 ? 4 : 8);
   const size_t nvec = a.npix * (size_t)vpc;
   const int g = grid_for_channels(nvec, vpc);
-  if (dtype == DT_F32) hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g), dim3(256), 0, st, a);
+  if (dtype == DT_F16) hipLaunchKernelGGL(bn_act_kernel<f16_t>, dim3(g), dim3(256), 0, st, a);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(bn_act_kernel<float>, dim3(g), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -289,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   }
 }
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const int VEC = dtype == DT_F32 ? 4 : 8;
   const int vpc = a.C / VEC;
   dim3 grid(a.rows, vpc >= 256 ? vpc / 256 : 1);
@@ -364,6 +387,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   }
 }
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const int vpc = a.C / (dtype == DT_F32 ? 4 : 8);
   const size_t nvec = a.npix * (size_t)vpc;
   const int g = grid_for_channels(nvec, vpc);
@@ -397,6 +421,7 @@ __global__ __launch_bounds__(256) void masked_accum_kernel(void* dst, const void
   }
 }
 hipError_t launch_masked_accum(int dtype, void* dst, const void* g, const void* out_mask, size_t n, int store, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const size_t nvec = n / (dtype == DT_F32 ? 4 : 8);
   const int gr = grid_for(nvec, 256);
   if (dtype == DT_F32) hipLaunchKernelGGL(masked_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, g, out_mask, nvec, store);
@@ -436,6 +461,7 @@ __global__ __launch_bounds__(256) void pool2x2_accum_kernel(void* dst, const voi
   }
 }
 hipError_t launch_pool2x2_accum(int dtype, void* dst, const void* src, int N, int H, int W, int C, int store, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
   if (dtype == DT_F32) hipLaunchKernelGGL(pool2x2_accum_kernel<float>, dim3(gr), dim3(256), 0, st, dst, src, N, H, W, C, store);
@@ -464,6 +490,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const void* g, size_t 
   }
 }
 hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride, int C, float* out, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const int gr = grid_for(npix, 256, 512);
   if (dtype == DT_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
   else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
@@ -509,7 +536,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* in, void* 
 hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, unsigned char* idx, int N, int H, int W, int C, hipStream_t st) {
   const size_t nvec = (size_t)N * (H / 2) * (W / 2) * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
+  if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16_t>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
   else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, in, out, idx, N, H, W, C);
   return hipGetLastError();
 }
@@ -561,6 +589,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned cha
 }
 hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const void* gout, void* gin, int N, int H, int W, int C, int store,
                                   hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
   if (dtype == DT_F32) hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(gr), dim3(256), 0, st, idx, gout, gin, N, H, W, C, store);
@@ -607,7 +636,9 @@ hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int
   const int gr = grid_for(nvec, 256);
   float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
   if (normalize) for (int i = 0; i < 3; ++i) { m[i] = mean[i]; iv[i] = 1.0f / stdv[i]; }
-  if (dtype == DT_F32)
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(stem_im2col_kernel<f16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
+  else if (dtype == DT_F32)
     hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
   else
     hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2]);
@@ -744,6 +775,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float g
   }
 }
 hipError_t launch_dice_bwd(int dtype, const DiceArgs& a, float grad_scale, void* dlogits, int CP, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
   if (a.C > CP || CP > 16 || CP % 8 != 0) return hipErrorInvalidValue;
   const size_t npix = (size_t)a.B * a.HW;
   const int gr = grid_for(npix, 256);
@@ -787,7 +819,9 @@ hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int ta
                                     const ConvPackInfo& p, hipStream_t st) {
   const size_t total = (size_t)taps * p.nchunks * p.ntiles * p.BN * (p.RB / 16);
   const int gr = grid_for(total, 256, 4096);
-  if (dtype == DT_F32)
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(pack_image_kernel<f16_t>, dim3(gr), dim3(256), 0, st, w, img, taps, O, I, transpose, p.BN, p.RB, p.nchunks, p.ntiles);
+  else if (dtype == DT_F32)
     hipLaunchKernelGGL(pack_image_kernel<float>, dim3(gr), dim3(256), 0, st, w, img, taps, O, I, transpose, p.BN, p.RB, p.nchunks, p.ntiles);
   else
     hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, w, img, taps, O, I, transpose, p.BN, p.RB, p.nchunks, p.ntiles);
@@ -797,7 +831,7 @@ hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int ta
 // All weight images of a plan in ONE launch: `tab` lists the jobs, `prefix[j]` = first global vector of job j.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char* ws, const PackJob* tab, const unsigned long long* prefix,
-                                                       int njobs, unsigned long long total) {
+                                                       int njobs, unsigned long long total, int fold) {
   constexpr int VEC = EV<T>::VEC;
   for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = njobs - 1;   // last job whose prefix <= g
@@ -818,22 +852,27 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char
     const int tap = (int)(rem / jb.nchunks);
     const int lq = q ^ ((row / swz_div) & (VPR - 1));
     const int co = nt * jb.BN + row, c0 = chunk * KC + lq * VEC;
+    // eval: the BatchNorm behind the conv is folded into its forward image, W'[o][i] = W[o][i] * scale[o] (the shift becomes the
+    // epilogue's bias): no lazy affine in any consumer's staging
+    float osc = 1.f;
+    if (fold && !jb.transpose && jb.scale_off != ~(size_t)0 && co < rows) osc = ((const float*)(ws + jb.scale_off))[co];
     float x[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const int c = c0 + i;
       float val = 0.f;
-      if (co < rows && c < K) val = jb.transpose ? w[((size_t)tap * jb.O + c) * jb.I + co] : w[((size_t)tap * jb.O + co) * jb.I + c];
+      if (co < rows && c < K) val = jb.transpose ? w[((size_t)tap * jb.O + c) * jb.I + co] : w[((size_t)tap * jb.O + co) * jb.I + c] * osc;
       x[i] = val;
     }
     stv<T>(ws + jb.dst_off, v, EV<T>::pack(x));
   }
 }
 hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
-                           unsigned long long total, hipStream_t st) {
+                           unsigned long long total, int fold, hipStream_t st) {
   const int gr = grid_for((size_t)total, 256, 8192);
-  if (dtype == DT_F32) hipLaunchKernelGGL(pack_all_kernel<float>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total);
-  else hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total);
+  if (dtype == DT_F16) hipLaunchKernelGGL(pack_all_kernel<f16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(pack_all_kernel<float>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
+  else hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
   return hipGetLastError();
 }
 

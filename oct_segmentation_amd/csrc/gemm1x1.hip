@@ -41,6 +41,7 @@ struct G1Args {
   char* y; long long ystride; int accum;
   int M, K, N, n_tiles, m_tiles;
   float* slab; int slab_row0;
+  const float* bias; int relu_out;       // eval with folded BatchNorm: y = relu?(acc + bias[n])
 };
 
 template <typename T, int NT, bool AFF>
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 
+  float obias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) obias[nt] = (a.bias != nullptr && n0 + nt * 32 + r < a.N) ? a.bias[n0 + nt * 32 + r] : 0.f;
+  const float ofloor = a.relu_out ? 0.f : -3.0e38f;
   const int bswz = (r >> 1) & 7;
   const int bbase = r * 128;
   const unsigned floor16 = a.relu ? 0u : 0x80008000u;
@@ -139,6 +144,12 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
 
   auto epilogue = [&]() __attribute__((always_inline)) {
     const int m0 = mt * G1_BM + wave * 32;
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nt][v] = fmaxf(acc[nt][v] + obias[nt], ofloor);
+    }
     if (a.slab != nullptr) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -287,7 +298,8 @@ bool gemm1x1_eligible(const ConvArgs& a, int dtype) {
   static const bool off = getenv("OCTSEG_NO_GEMM1X1") != nullptr;   // A/B switch
   if (off || dtype == DT_F32) return false;
   if (a.ntaps != 1 || a.istride != 1 || a.ostride != 1 || a.out_mode == OUT_HEAD_NCHW) return false;
-  if (a.tap_dy[0] != 0 || a.tap_dx[0] != 0 || a.nsrc != 1 || a.ndst != 1 || a.bias != nullptr) return false;
+  if (a.tap_dy[0] != 0 || a.tap_dx[0] != 0 || a.nsrc != 1 || a.ndst != 1) return false;
+  if (a.bias != nullptr && a.stat_slab != nullptr) return false;   // (bias only as the folded BatchNorm shift of eval forwards)
   const SrcDesc& s = a.src[0];
   const DstDesc& d = a.dst[0];
   if (s.up || s.C != a.Cin || s.c0 != 0 || s.H != a.IH || s.W != a.IW || a.IH != a.OH || a.IW != a.OW) return false;
@@ -324,8 +336,15 @@ hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t st) {
   ga.y = (char*)d.ptr; ga.ystride = (long long)d.C * 2; ga.accum = (d.accum || a.out_mode == OUT_ACCUM) ? 1 : 0;
   ga.M = (int)((long long)a.N * a.OH * a.OW); ga.K = a.Cin; ga.N = a.Cout; ga.n_tiles = g.n_tiles; ga.m_tiles = g.m_tiles;
   ga.slab = a.stat_slab; ga.slab_row0 = a.slab_row0;
+  ga.bias = a.bias; ga.relu_out = a.relu_out;
   const bool aff = s.scale != nullptr;
-  (void)dtype;
+  if (dtype == DT_F16) {
+    switch (g.NT) {
+      case 4: return g1_launch<f16_t, 4>(ga, g, aff, st);
+      case 2: return g1_launch<f16_t, 2>(ga, g, aff, st);
+      default: return g1_launch<f16_t, 1>(ga, g, aff, st);
+    }
+  }
   switch (g.NT) {
     case 4: return g1_launch<bf16_t, 4>(ga, g, aff, st);
     case 2: return g1_launch<bf16_t, 2>(ga, g, aff, st);

@@ -39,7 +39,8 @@ hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta,
                                    hipStream_t st);
 
 // eval: scale/shift of every BatchNorm of a plan in one launch (job table + channel prefix sums in the workspace)
-struct BnEvalJob { size_t gamma_off, beta_off, rm_off, rv_off /*floats*/, ss_off /*bytes*/; int C; };
+struct BnEvalJob { size_t gamma_off, beta_off, rm_off, rv_off /*floats*/, ss_off /*bytes*/; int C;
+                   size_t bias_off; /* floats: bias of the conv in front of this BN, folded into the shift (~0: none) */ };
 hipError_t launch_bn_finalize_eval_all(const float* params, const float* buffers, void* ws, const BnEvalJob* tab, const unsigned* prefix,
                                        int njobs, unsigned total, float eps, hipStream_t st);
 
@@ -106,9 +107,11 @@ hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int ta
                                     const ConvPackInfo& p, hipStream_t st);
 
 // every weight image of a plan in one launch (job table + prefix sums live in the workspace)
-struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, transpose, BN, RB, nchunks, ntiles; };
+struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, transpose, BN, RB, nchunks, ntiles;
+                 size_t scale_off; /* bytes in the workspace: eval scale[O] of the BatchNorm behind this conv, folded into the
+                                      forward image when packing for eval (~0: none) */ };
 hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
-                           unsigned long long total, hipStream_t st);
+                           unsigned long long total, int fold, hipStream_t st);
 
 // serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,

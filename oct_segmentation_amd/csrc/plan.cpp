@@ -521,6 +521,7 @@ static int build_plan(octseg_plan* P) {
         }
         DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; dd.C = L.Cout; dd.cn = L.Cout; a.dst[0] = dd; a.ndst = 1;
         a.bias = L.b >= 0 ? (const float*)(uintptr_t)16 : nullptr;   // presence only
+        a.stat_slab = (float*)(uintptr_t)16;                          // (the rows are those of a TRAINING forward)
         a.out_mode = L.head ? OUT_HEAD_NCHW : OUT_STORE;
         rows += conv_num_mtiles_flat(a, P->dtype);
       }
@@ -537,7 +538,8 @@ static int build_plan(octseg_plan* P) {
     for (int tr = 0; tr < 2; ++tr) {
       if (tr == 1 && !L.has_dgrad) continue;
       const ConvPackInfo& pk = tr ? L.pk_dgrad : L.pk_fwd;
-      PackJob j{P->params[L.w].off, tr ? L.wimg_dgrad_off : L.wimg_fwd_off, taps, L.Cout, L.Cin, tr, pk.BN, pk.RB, pk.nchunks, pk.ntiles};
+      PackJob j{P->params[L.w].off, tr ? L.wimg_dgrad_off : L.wimg_fwd_off, taps, L.Cout, L.Cin, tr, pk.BN, pk.RB, pk.nchunks, pk.ntiles,
+                (!tr && L.bn >= 0) ? P->bns[L.bn].ss_off : ~(size_t)0};
       P->pack_prefix.push_back(P->pack_total);
       P->pack_jobs.push_back(j);
       P->pack_total += (unsigned long long)taps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
@@ -546,9 +548,11 @@ static int build_plan(octseg_plan* P) {
   P->bn_jobs.clear(); P->bn_prefix.clear(); P->bn_total = 0;
   for (auto& b : P->bns) {
     P->bn_prefix.push_back(P->bn_total);
-    P->bn_jobs.push_back(BnEvalJob{P->params[b.gamma].off, P->params[b.beta].off, b.rm_off, b.rv_off, b.ss_off, b.C});
+    P->bn_jobs.push_back(BnEvalJob{P->params[b.gamma].off, P->params[b.beta].off, b.rm_off, b.rv_off, b.ss_off, b.C, ~(size_t)0});
     P->bn_total += (unsigned)b.C;
   }
+  for (auto& L : P->convs)   // a biased conv in front of a BatchNorm (LinkNet's ConvTranspose2d): its bias folds into the eval shift
+    if (L.bn >= 0 && L.b >= 0) P->bn_jobs[L.bn].bias_off = P->params[L.b].off;
   P->bn_tab_off = off; off += align_up(P->bn_jobs.size() * sizeof(BnEvalJob));
   P->bn_prefix_off = off; off += align_up(P->bn_prefix.size() * sizeof(unsigned));
   P->pack_tab_off = off; off += align_up(P->pack_jobs.size() * sizeof(PackJob));
@@ -624,9 +628,14 @@ static double layer_macs(const ConvLayer& L) {
   return (double)L.N * L.OH * L.OW * L.Cout * (L.stem ? 147.0 : (double)L.Cin * (L.transposed ? 4.0 : (double)L.R * L.S));
 }
 
-static int pack_all_weights(Exec& E) {
+// fold = 1 (eval forwards): scale / shift of every BatchNorm from the running statistics first (one launch), then every forward
+// image with its BatchNorm's scale folded in (reference: what conv + BN in eval mode computes, src/predict.py / model.py:183-200);
+// fold = 0 (training): plain images.  Cached until the parameters / buffers change or the mode flips.
+static int pack_all_weights(Exec& E, bool fold) {
   octseg_plan* P = E.P;
-  if (P->packed_valid && P->packed_ws == (const void*)E.ws && P->packed_params == (const void*)E.params) return OCTSEG_OK;
+  if (P->packed_valid && P->packed_fold == fold && P->packed_ws == (const void*)E.ws && P->packed_params == (const void*)E.params &&
+      (!fold || P->packed_buffers == (const void*)E.buffers))
+    return OCTSEG_OK;
   if (P->pack_tab_ws != (const void*)E.ws) {   // first use of this workspace: upload the job table
     HIPCHK(hipMemcpyAsync(E.ws + P->pack_tab_off, P->pack_jobs.data(), P->pack_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, E.st));
     HIPCHK(hipMemcpyAsync(E.ws + P->pack_prefix_off, P->pack_prefix.data(), P->pack_prefix.size() * sizeof(unsigned long long),
@@ -637,9 +646,12 @@ static int pack_all_weights(Exec& E) {
     }
     P->pack_tab_ws = E.ws;
   }
+  if (fold && !P->bn_jobs.empty())
+    HIPCHK(launch_bn_finalize_eval_all(E.params, E.buffers, E.ws, (const BnEvalJob*)(E.ws + P->bn_tab_off),
+                                       (const unsigned*)(E.ws + P->bn_prefix_off), (int)P->bn_jobs.size(), P->bn_total, 1e-5f, E.st));
   HIPCHK(launch_pack_all(P->dtype, E.params, E.ws, (const PackJob*)(E.ws + P->pack_tab_off),
-                         (const unsigned long long*)(E.ws + P->pack_prefix_off), (int)P->pack_jobs.size(), P->pack_total, E.st));
-  P->packed_valid = true; P->packed_ws = E.ws; P->packed_params = E.params;
+                         (const unsigned long long*)(E.ws + P->pack_prefix_off), (int)P->pack_jobs.size(), P->pack_total, fold ? 1 : 0, E.st));
+  P->packed_valid = true; P->packed_fold = fold; P->packed_ws = E.ws; P->packed_params = E.params; P->packed_buffers = E.buffers;
   return OCTSEG_OK;
 }
 
@@ -656,14 +668,12 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
                  t.N, t.C, t.H, t.W);
         return fail(OCTSEG_BAD_SHAPE, buf);
       }
-  int rc = pack_all_weights(E);
+  int rc = pack_all_weights(E, !E.train);
   if (rc) return rc;
   if (E.train) HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 2 * 64 * sizeof(unsigned), E.st));
-  // eval: the running statistics are all known up front -> scale/shift of every BatchNorm in ONE launch
-  // (a B=1 predict is launch-latency bound: 126 tiny kernels less per forward)
-  if (!E.train && !P->bn_jobs.empty())
-    HIPCHK(launch_bn_finalize_eval_all(E.params, E.buffers, E.ws, (const BnEvalJob*)(E.ws + P->bn_tab_off),
-                                       (const unsigned*)(E.ws + P->bn_prefix_off), (int)P->bn_jobs.size(), P->bn_total, 1e-5f, E.st));
+  // eval: BatchNorm is folded -- scale into the weight images (pack_all_weights), shift into the conv epilogue's bias, ReLU into
+  // the epilogue of every conv whose BatchNorm is only read through relu(bn(y)): consumers stage plain activations
+  const bool folded = !E.train;
   // ---- forward lanes (assign_lanes): lane-1 ops go to the side stream; a lane waits for the other one only when it
   // reads something the other lane produced and has not synchronised with since
   static const bool no_lanes = getenv("OCTSEG_NO_FWD_LANES") != nullptr;
@@ -721,6 +731,10 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.nsrc = E.fill_srcs(L, a.src);
           a.W = fwd_weight(E, L);
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
+          if (folded) {
+            for (int i = 0; i < a.nsrc; ++i) { a.src[i].scale = nullptr; a.src[i].shift = nullptr; a.src[i].relu = 0; }
+            if (L.bn >= 0) { a.bias = E.bn_shift(L.bn); a.relu_out = P->bns[L.bn].lazy ? 1 : 0; }
+          }
           a.ndst = 1;
           DstDesc d;
           d.accum = 0; d.pool = 0;
@@ -759,10 +773,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         if (op.post >= 0) { rc = need(lane, tseq[op.post]); if (rc) return rc; }
         BnActArgs a;
         memset(&a, 0, sizeof(a));
-        a.y = E.act(op.y.t); a.scale = E.bn_scale(op.y.bn); a.shift = E.bn_shift(op.y.bn);
+        a.y = E.act(op.y.t);
+        if (!folded) { a.scale = E.bn_scale(op.y.bn); a.shift = E.bn_shift(op.y.bn); }
         if (op.res.t >= 0) {
           a.res = E.act(op.res.t);
-          if (op.res.bn >= 0) { a.rscale = E.bn_scale(op.res.bn); a.rshift = E.bn_shift(op.res.bn); }
+          if (op.res.bn >= 0 && !folded) { a.rscale = E.bn_scale(op.res.bn); a.rshift = E.bn_shift(op.res.bn); }
         }
         if (op.post >= 0) a.post = E.act(op.post);
         a.out = E.act(op.out); a.npix = (size_t)t.N * t.H * t.W; a.C = t.C; a.relu = op.relu;
@@ -1068,7 +1083,7 @@ const char* octseg_last_error(void) { return g_err.c_str(); }
 int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   if (!d || !out) return fail(OCTSEG_BAD_ARG, "null argument");
   *out = nullptr;
-  if (d->dtype != OCTSEG_F32 && d->dtype != OCTSEG_BF16) return fail(OCTSEG_BAD_DTYPE, "dtype must be f32 or bf16");
+  if (d->dtype != OCTSEG_F32 && d->dtype != OCTSEG_BF16 && d->dtype != OCTSEG_F16) return fail(OCTSEG_BAD_DTYPE, "dtype must be f32, bf16 or f16");
   if (d->height <= 0 || d->width <= 0 || d->height % 32 != 0 || d->width % 32 != 0) {
     char buf[256];
     snprintf(buf, sizeof buf, "Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.",
@@ -1177,6 +1192,8 @@ int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void
                        float* logits, int normalize, const float* mean, const float* stdv, int train, void* stream) {
   if (!p || !params || !buffers || !workspace || !image || !logits) return fail(OCTSEG_BAD_ARG, "null argument");
   if (normalize && (!mean || !stdv)) return fail(OCTSEG_BAD_ARG, "normalize=1 needs mean/std");
+  if (train && p->dtype == OCTSEG_F16)
+    return fail(OCTSEG_BAD_DTYPE, "f16 is a serving dtype (eval forwards, reference predict.py); train in bf16 or f32");
   Exec E{p, params, nullptr, buffers, (char*)workspace, (hipStream_t)stream, train};
   if (train || !p->graph_enabled) return run_forward(E, image, logits, normalize, mean, stdv);
   // ---- eval forward through a hipGraph
@@ -1187,7 +1204,7 @@ int octseg_net_forward(octseg_plan* p, const float* params, float* buffers, void
     p->graph_key = key; p->graph_seen = 0;
   }
   // weight images are packed outside the graph (a replay never repacks; octseg_plan_params_changed brings us here)
-  int rc = pack_all_weights(E);
+  int rc = pack_all_weights(E, true);
   if (rc) return rc;
   if (p->graph_exec) { HIPCHK(hipGraphLaunch(p->graph_exec, E.st)); return OCTSEG_OK; }
   if (p->graph_seen++ == 0) return run_forward(E, image, logits, normalize, mean, stdv);   // eager warm-up call
@@ -1251,6 +1268,7 @@ int octseg_dice_forward(octseg_plan* p, void* workspace, const float* logits, co
 int octseg_net_backward(octseg_plan* p, const float* params, float* grads, void* workspace, const float* logits,
                         const float* target, float grad_scale, void* stream) {
   if (!p || !params || !grads || !workspace || !logits || !target) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (p->dtype == OCTSEG_F16) return fail(OCTSEG_BAD_DTYPE, "f16 is a serving dtype: no backward");
   Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
   return run_backward(E, logits, target, grad_scale);
 }
@@ -1266,6 +1284,7 @@ int octseg_net_backward_sliced(octseg_plan* p, const float* params, float* grads
                                octseg_slice_cb cb, void* user) {
   if (!p || !params || !grads || !workspace || !logits || !target || !cb) return fail(OCTSEG_BAD_ARG, "null argument");
   if (nslices < 1 || nslices > 64) return fail(OCTSEG_BAD_ARG, "1 <= nslices <= 64 required");
+  if (p->dtype == OCTSEG_F16) return fail(OCTSEG_BAD_DTYPE, "f16 is a serving dtype: no backward");
   if (!comm_stream || comm_stream == stream) return fail(OCTSEG_BAD_ARG, "comm_stream must be a stream of its own");
   Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
   SliceCtx S;

@@ -97,6 +97,8 @@ struct octseg_plan {
   // beside the dgrad / BN-backward chain (MFMA-bound next to HBM-bound work)
   // weight images currently in the workspace correspond to (packed_params, packed_ws) unless invalidated
   bool packed_valid = false;
+  bool packed_fold = false;                // eval images (BatchNorm scale folded in) vs training images
+  const void* packed_buffers = nullptr;    // running statistics the eval images were folded with
   const void* packed_ws = nullptr;
   const void* packed_params = nullptr;
   std::vector<octseg::PackJob> pack_jobs;          // host copy of the pack table

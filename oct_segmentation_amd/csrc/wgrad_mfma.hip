@@ -500,6 +500,8 @@ static void flatten_1x1(WgradArgs& a) {
 }
 
 hipError_t launch_wgrad(int dtype, const WgradArgs& a0, hipStream_t st) {
+  if (dtype == DT_F16) return hipErrorInvalidValue;   // f16 is an eval-forward dtype
+
   if (a0.ntaps <= 0) return hipSuccess;
   WgradArgs a = a0;
   flatten_1x1(a);

@@ -32,7 +32,9 @@ def _dtype_code(dtype):
         return L.F32
     if dtype in (torch.bfloat16, 'bf16', 'bfloat16'):
         return L.BF16
-    raise TypeError(f'compute dtype must be float32 or bfloat16, got {dtype}')
+    if dtype in (torch.float16, 'fp16', 'f16', 'float16', 'half'):
+        return L.F16   # serving only (eval forwards): BASELINE config #5
+    raise TypeError(f'compute dtype must be float32, bfloat16 or float16, got {dtype}')
 
 
 class _Plan:
@@ -307,7 +309,7 @@ class SegNet(nn.Module):
         plan.generation += 1   # this forward overwrites the plan's saved activations / BN statistics / Dice sums
         # in-place writes to the arena (torch optimizers, copy_, all-reduce) bump its version counter; the fused
         # optimizer calls params_changed() itself.  A changed version invalidates every plan's weight images.
-        ver = (self.arena._version, self._param_epoch)
+        ver = (self.arena._version, self.bn_buffers._version, self._param_epoch)   # (eval weight images fold the running statistics in)
         if getattr(plan, 'seen_version', None) != ver:
             L.check(L.lib().octseg_plan_params_changed(plan.handle))
             plan.seen_version = ver
@@ -404,5 +406,5 @@ def debug_tensor(net, plan, conv_name, grad=False):
     esz = 4 if net.dtype_code == L.F32 else 2
     off = gr.value if grad else act.value
     raw = plan.workspace[off:off + N * H * W * Cc * esz]
-    t = raw.view(torch.float32 if esz == 4 else torch.bfloat16).view(N, H, W, Cc)
+    t = raw.view(torch.float32 if esz == 4 else (torch.float16 if net.dtype_code == L.F16 else torch.bfloat16)).view(N, H, W, Cc)
     return t.float().permute(0, 3, 1, 2).contiguous()

@@ -14,7 +14,9 @@ def _dt(t):
         return L.F32
     if t.dtype == torch.bfloat16:
         return L.BF16
-    raise TypeError(f'unsupported dtype {t.dtype}: float32 or bfloat16 expected')
+    if t.dtype == torch.float16:
+        return L.F16   # forward only
+    raise TypeError(f'unsupported dtype {t.dtype}: float32, bfloat16 or float16 expected')
 
 
 def weight_to_arena(w, transposed=False):

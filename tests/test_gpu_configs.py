@@ -109,8 +109,8 @@ def test_c4_unet_resnet50_704_bf16_with_gpu_augmentation(cuda):
 
 
 def test_c5_ensemble_704_graph_replay(cuda, tmp_path):
-    """BASELINE configs[4]: LM (U-Net++/resnet101) + FC_LC (LinkNet/resnet50, 2 classes) + VV (U-Net/resnet50) on 704x704 frames
-    through segment() with every eval forward replayed from a captured hipGraph: equal to the eager masks bit for bit, the
+    """BASELINE configs[4]: LM (U-Net++/resnet101) + FC_LC (LinkNet/resnet50, 2 classes) + VV (U-Net/resnet50) on 704x704 frames in
+    fp16 through segment() with every eval forward replayed from a captured hipGraph: equal to the eager masks bit for bit, the
     4-channel stack follows CLASS_IDS - 1 and the FC_LC channel mapping of MODELS_META (predict.py:23-28)."""
     from PIL import Image
     from oct_segmentation_amd.model import OCTSegmentationModel
@@ -132,7 +132,8 @@ def test_c5_ensemble_704_graph_replay(cuda, tmp_path):
     outs = []
     for use_graph in (False, True):
         masks = [np.zeros((1000, 1000, 4)) for _ in images]
-        outs.append(segment(images, masks, [1000, 1000], classes, str(tmp_path), device='cuda', batch_size=1, use_graph=use_graph))
+        outs.append(segment(images, masks, [1000, 1000], classes, str(tmp_path), device='cuda', batch_size=1, use_graph=use_graph,
+                            compute_dtype=torch.float16))
     for a, b in zip(*outs):
         assert a.shape == (1000, 1000, 4) and set(np.unique(a)) <= {0.0, 1.0}
         assert np.array_equal(a, b)

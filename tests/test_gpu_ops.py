@@ -101,3 +101,26 @@ def test_conv_bias_and_identity(cuda):
                             b.to(cuda), 1, 0, False)
     torch.cuda.synchronize()
     assert _rel(yd.cpu().permute(0, 3, 1, 2), y) < 1e-6
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[3], CASES[4], CASES[6], CASES[7], CASES[12], CASES[13]], ids=str)
+def test_conv_forward_f16(cuda, case):
+    """IEEE half storage (OCTSEG_F16, the serving dtype of BASELINE config #5): forward of every conv family against torch on the
+    same f16-quantised operands, f32 accumulate -> 2e-3 of the output scale; the backward entry points refuse the dtype."""
+    from oct_segmentation_amd import ops
+    N, H, W, Cin, Cout, R, stride, pad, tr = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, Cin, H, W, generator=g).half().float()
+    wshape = (Cin, Cout, R, R) if tr else (Cout, Cin, R, R)
+    w = (torch.randn(wshape, generator=g) / (Cin * R * R) ** 0.5).half().float()
+    y = _ref(x, w, stride, pad, tr)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda, torch.float16)
+    wa = ops.weight_to_arena(w, tr).to(cuda)
+    yd = ops.conv2d_forward(xd, wa, None, stride, pad, tr)
+    torch.cuda.synchronize()
+    assert yd.dtype == torch.float16
+    e = _rel(yd.float().cpu().permute(0, 3, 1, 2), y)
+    print(f'f16 case={case} fwd={e:.3e}')
+    assert e < 2e-3
+    with pytest.raises(RuntimeError):
+        ops.conv2d_backward_weight(xd, yd, R, stride, pad, tr)
