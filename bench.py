@@ -122,21 +122,114 @@ def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
                       f'time budget): fp32 {[round(t, 2) for t in t32]} s, bf16 autocast {[round(t, 2) for t in t16]} s'}
 
 
+ENSEMBLE = (('LM', 'unetplusplus', 'resnet101', ['Lumen']), ('FC_LC', 'linknet', 'resnet50', ['Lipid core', 'Fibrous cap']),
+            ('VV', 'unet', 'resnet50', ['Vasa vasorum']))
+
+
+def bench_ensemble(args):
+    """BASELINE config #5: the predict.py path -- LM (U-Net++/resnet101) + FC_LC (LinkNet/resnet50, 2 classes) + VV (U-Net/resnet50)
+    eval forwards in fp16 on `--batch` 704x704 frames (no normalisation, reference model.py:192), each net once per batch (the
+    reference runs FC_LC twice), sigmoid > 0.5 + cv2-nearest resize to 1000x1000 + 4-channel mask assembly on the GPU
+    (octseg_mask_assemble, predict.py:92-100).  One step = one batch through all three nets and the epilogue; frames resident in
+    HBM.  Replayed hipGraphs unless --no-graph."""
+    import ctypes as C
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.engine import SegNet
+    from oct_segmentation_amd.model import CLASS_IDS
+    from oct_segmentation_amd.predict import MODELS_META, cv2_nearest_index
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    B, S, OUT = args.batch, 704, 1000
+    cdt = {'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32}[args.dtype]
+    nets = []
+    for i, (_, arch, enc, classes) in enumerate(ENSEMBLE):
+        net = SegNet(arch, enc, classes=len(classes), device=dev, compute_dtype=cdt, seed=40 + i).eval()
+        net.use_graph = not args.no_graph
+        nets.append((net, classes))
+    from synth import make_batch
+    x = make_batch(B, 1, S, seed=7)[0].to(dev)
+    stack = torch.zeros((B, OUT, OUT, 4), dtype=torch.float32, device=dev)
+    rows = torch.from_numpy(cv2_nearest_index(S, OUT)).to(dev)
+    lib = L.lib()
+
+    def step():
+        for net, classes in nets:
+            if os.environ.get('OCTSEG_BENCH_TRACE'):
+                print(f'[bench] {net.arch}/{net.encoder_name}', file=sys.stderr, flush=True)
+            z = net(x, normalize=False)
+            for cl in classes:
+                ch = MODELS_META[cl]['index'] if z.shape[1] > 1 else 0
+                L.check(lib.octseg_mask_assemble(L.ptr(z), B, z.shape[1], S, S, int(ch), L.ptr(stack), OUT, OUT, 4, CLASS_IDS[cl] - 1,
+                                                 L.ptr(rows), L.ptr(rows), L.stream_ptr()))
+
+    print(f'[bench] ensemble of 3 nets, {B} frame(s) per step, {args.dtype}, {"hipGraph replay" if not args.no_graph else "eager"}: warm-up',
+          file=sys.stderr, flush=True)
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # roofline pass: eager, one stream, every conv launch bracketed by HIP events
+    for net, _ in nets:
+        net.use_graph = False
+    prof = (C.c_double * 12)()
+    L.check(lib.octseg_debug_set_serial(1))
+    step(); torch.cuda.synchronize()
+    L.check(lib.octseg_profile_start())
+    n_alone = 3
+    for _ in range(n_alone):
+        step()
+    torch.cuda.synchronize()
+    L.check(lib.octseg_profile_stop(prof))
+    L.check(lib.octseg_debug_set_serial(0))
+    macs = sum(net.fwd_macs(B, S, S) for net, _ in nets) / B
+    ach = prof[1] / (prof[0] * 1e-3) / 1e12 if prof[0] > 0 else 0.0
+    peak = 157.3 if args.dtype == 'fp32' else 2500.0
+    out = {'metric': 'OCT frames/sec (704x704, fp16) 3-net ensemble inference', 'value': round(B * args.steps / dt, 3), 'unit': 'frames/s',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 3), 'ms_per_step': round(dt / args.steps * 1e3, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+           'data': 'synthetic OCT-shaped frames (seeded), random-init weights',
+           'config': {'workload': f'ensemble LM unetplusplus/resnet101 + FC_LC linknet/resnet50 (2 classes) + VV unet/resnet50, 704x704 -> 4-class '
+                                  f'1000x1000 masks, batch {B}, eval forward + GPU mask assembly, {"hipGraph replay" if not args.no_graph else "eager launches"}',
+                      'global_batch': B, 'parallelism': 'dp1', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
+           'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel (forward, BatchNorm folded)', 'achieved': round(ach, 2),
+                        'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                        'launches_per_step': round(prof[2] / n_alone, 1), 'kernel_ms_per_step': round(prof[0] / n_alone, 3),
+                        'avg_launch_ms': round(prof[0] / max(prof[2], 1.0), 4), 'algorithmic_gflop_per_frame': round(2 * macs / 1e9, 1),
+                        'note': 'HIP-event brackets of every conv launch in an untimed eager one-stream pass of the same step'}}
+    print(f'[bench] ensemble: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; conv kernels alone {ach:.1f} TFLOP/s', file=sys.stderr, flush=True)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='unetpp_r101_704', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='unetpp_r101_704', choices=sorted(WORKLOADS) + ['ensemble_704_fp16'])
+    ap.add_argument('--no-graph', action='store_true', help='ensemble workload: eager launches instead of replayed hipGraphs')
     ap.add_argument('--batch', type=int, default=16, help='frames per GPU (weak scaling) / frames in the global batch (strong scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: --batch frames per GPU whatever N; strong: the global batch stays --batch, every GPU gets batch/N frames')
     ap.add_argument('--allreduce-slices', type=int, default=3, help='gradient-arena slices all-reduced beside the backward (N > 1)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp32', 'fp16'], help='default: bf16 (training workloads), fp16 (ensemble)')
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)')
     args = ap.parse_args()
+    if args.workload == 'ensemble_704_fp16':
+        args.dtype = args.dtype or 'fp16'
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback)')
+        if args.batch == 16 and '--batch' not in ' '.join(sys.argv):
+            args.batch = 1     # the reference's predict loop is frame by frame (predict.py:85-91)
+        return bench_ensemble(args)
+    args.dtype = args.dtype or 'bf16'
+    if args.dtype == 'fp16':
+        raise SystemExit('fp16 is the serving dtype (--workload ensemble_704_fp16); training runs in bf16 or fp32')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -315,13 +315,18 @@ class SegNet(nn.Module):
             plan.seen_version = ver
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
-        if self.use_graph and not train:
+        want_graph = bool(self.use_graph and not train)
+        if getattr(plan, 'graph_on', False) != want_graph and (want_graph or getattr(plan, 'graph_io', None) is not None):
+            # the plan captures every eval forward while its graph mode is on -- also one issued eagerly on another stream
+            # (use_graph switched off again): keep the C-side switch in step with the Python one
+            L.check(L.lib().octseg_plan_set_graph(plan.handle, 1 if want_graph else 0))
+            plan.graph_on = want_graph
+        if want_graph:
             # serving path: the plan replays a captured hipGraph as long as every pointer stays the same, so the
             # frame goes through a persistent input buffer and the logits come back as a copy of a persistent one
             if getattr(plan, 'graph_io', None) is None:
                 plan.graph_io = (torch.empty_like(x), torch.empty((B, self.classes, H, W), dtype=torch.float32, device=x.device),
                                  torch.cuda.Stream(device=x.device))   # the legacy default stream cannot be captured
-                L.check(L.lib().octseg_plan_set_graph(plan.handle, 1))
             gin, gout, gstream = plan.graph_io
             cur = torch.cuda.current_stream(x.device)
             gin.copy_(x)
