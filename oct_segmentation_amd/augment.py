@@ -84,6 +84,7 @@ def sample_frame(S, rng, crop_frac=None):
         M = P @ M
         post = P @ post
         log['perspective'] = s
+        log['perspective_matrix'] = P
     alpha, beta = 1.0, 0.0
     sigma, seed = 0.0, 0
     if rng.random() < P_NOISE:

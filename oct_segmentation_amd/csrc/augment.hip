@@ -5,8 +5,8 @@
 // (oct_segmentation_amd/augment.py mirrors the probabilities and ranges), composes every geometric transform
 // (HorizontalFlip, ShiftScaleRotate, RandomCrop + centred PadIfNeeded, Perspective) into ONE inverse homography, and a
 // single kernel produces the augmented frame: one bilinear gather of the image (constant-0 border), one nearest gather
-// of every mask channel, then GaussNoise, RandomBrightnessContrast and HueSaturationValue on the pixel, clipped and
-// rounded to the uint8 grid the reference's images live on.  One interpolation instead of up to three: statistical, not
+// of every mask channel, then GaussNoise, RandomBrightnessContrast and HueSaturationValue on the pixel, each quantised to
+// the uint8 grid the way the reference's stage does it (round / truncate / OpenCV's 8-bit HSV arithmetic).  One interpolation instead of up to three: statistical, not
 // bit, parity with the reference -- which is what section 8 asks of this row.
 #include "common.h"
 #include "kernels.h"
@@ -22,33 +22,45 @@ __device__ __forceinline__ unsigned hash3(unsigned a, unsigned b, unsigned c) { 
 }
 __device__ __forceinline__ float u01(unsigned h) { return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// OpenCV's 8-bit BGR <-> HSV (H in [0, 180), S and V in [0, 255]), in float
-__device__ __forceinline__ void bgr2hsv(float b, float g, float r, float& h, float& s, float& v) {
-  v = fmaxf(r, fmaxf(g, b));
-  const float mn = fminf(r, fminf(g, b)), d = v - mn;
-  s = v > 0.f ? 255.f * d / v : 0.f;
-  if (d <= 0.f) { h = 0.f; return; }
-  float hh;
-  if (v == r) hh = (g - b) / d;
-  else if (v == g) hh = 2.f + (b - r) / d;
-  else hh = 4.f + (r - g) / d;
-  hh *= 30.f;                       // 60 degrees / 2
-  if (hh < 0.f) hh += 180.f;
+// OpenCV's 8-bit RGB <-> HSV as albumentations' HueSaturationValue runs it on uint8 frames (cv2.cvtColor COLOR_RGB2HSV ->
+// integer LUT shifts -> COLOR_HSV2RGB; albumentations 1.4.3 _shift_hsv_uint8).  Forward = imgproc color_hsv RGB2HSV_b: integer
+// arithmetic, H in [0, 180) and S, V in [0, 255] quantised to 8 bits, divisions through 12-bit fixed-point reciprocal tables
+// (sdiv_table[v] = round(255 * 4096 / v), hdiv_table180[d] = round(180 * 4096 / (6 d))).  c0 / c1 / c2 are the "R" / "G" / "B" of
+// that call: the reference hands its BGR frames to albumentations, which takes channel 0 for red -- mirrored here on purpose.
+__device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& h, int& s, int& v) {
+  v = max(r, max(g, b));
+  const int vmin = min(r, min(g, b)), diff = v - vmin;
+  const int sdiv = v > 0 ? __double2int_rn((255.0 * 4096.0) / (double)v) : 0;
+  const int hdiv = diff > 0 ? __double2int_rn((180.0 * 4096.0) / (6.0 * (double)diff)) : 0;
+  s = (diff * sdiv + 2048) >> 12;
+  int hh;
+  if (v == r) hh = g - b;
+  else if (v == g) hh = b - r + 2 * diff;
+  else hh = r - g + 4 * diff;
+  hh = (hh * hdiv + 2048) >> 12;
+  if (hh < 0) hh += 180;
   h = hh;
 }
-__device__ __forceinline__ void hsv2bgr(float h, float s, float v, float& b, float& g, float& r) {
-  const float hh = h / 30.f, ss = s / 255.f;
-  const int sector = ((int)floorf(hh)) % 6;
-  const float f = hh - floorf(hh);
-  const float p = v * (1.f - ss), q = v * (1.f - ss * f), t = v * (1.f - ss * (1.f - f));
-  switch (sector) {
-    case 0: r = v; g = t; b = p; break;
-    case 1: r = q; g = v; b = p; break;
-    case 2: r = p; g = v; b = t; break;
-    case 3: r = p; g = q; b = v; break;
-    case 4: r = t; g = p; b = v; break;
-    default: r = v; g = p; b = q; break;
+// Backward = HSV2RGB_b: through float (H * 6/180, S / 255, V / 255), the sector table of HSV2RGB_native, saturate_cast<uchar>(x * 255)
+__device__ __forceinline__ void hsv2rgb_u8(int h, int s, int v, int& r, int& g, int& b) {
+  const float fs = (float)s * (1.f / 255.f), fv = (float)v * (1.f / 255.f);
+  float fr, fg, fb;
+  if (s == 0) { fr = fg = fb = fv; }
+  else {
+    float hh = (float)h * (6.f / 180.f);
+    if (hh < 0.f) { do hh += 6.f; while (hh < 0.f); }
+    else if (hh >= 6.f) { do hh -= 6.f; while (hh >= 6.f); }
+    int sector = (int)floorf(hh);
+    hh -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; hh = 0.f; }
+    const float tab[4] = {fv, fv * (1.f - fs), fv * (1.f - fs * hh), fv * (1.f - fs * (1.f - hh))};
+    // sector_data[sector] = indices of (b, g, r) in tab
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    fb = tab[sd[sector][0]]; fg = tab[sd[sector][1]]; fr = tab[sd[sector][2]];
   }
+  r = min(max(__float2int_rn(fr * 255.f), 0), 255);
+  g = min(max(__float2int_rn(fg * 255.f), 0), 255);
+  b = min(max(__float2int_rn(fb * 255.f), 0), 255);
 }
 
 }  // namespace
@@ -87,28 +99,44 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* img, const fl
       const float bot = at(y0 + 1, x0) * (1.f - ax) + at(y0 + 1, x0 + 1) * ax;
       px[c] = in_crop ? top * (1.f - ay) + bot * ay : 0.f;
     }
-    // ---- GaussNoise (per channel), RandomBrightnessContrast, HueSaturationValue: on the 0..255 BGR pixel
+    // ---- GaussNoise (per channel), RandomBrightnessContrast, HueSaturationValue on the 0..255 pixel.  The reference's frames are
+    // uint8 between the transforms: a warp rounds to nearest (cv2 fixed-point interpolation), GaussNoise and
+    // RandomBrightnessContrast clip and TRUNCATE (albumentations `np.clip(...).astype(uint8)`), HueSaturationValue runs OpenCV's 8-bit
+    // HSV round trip -- each stage is quantised the same way here
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[c] = rintf(fminf(fmaxf(px[c], 0.f), 255.f));
     const float sigma = p[11];
     if (sigma > 0.f) {
       const unsigned seed = __float_as_uint(p[12]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float u1 = u01(hash3(seed, (unsigned)i, 2u * c)), u2 = u01(hash3(seed, (unsigned)i, 2u * c + 1u));
-        px[c] += sigma * sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
+        px[c] = floorf(fminf(fmaxf(px[c] + sigma * sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2), 0.f), 255.f));
       }
     }
+    if (p[9] != 1.f || p[10] != 0.f) {   // the LUT of _brightness_contrast_adjust_uint: float32 arange * alpha + beta * 255, clipped, truncated
 #pragma unroll
-    for (int c = 0; c < 3; ++c) px[c] = fminf(fmaxf(px[c] * p[9] + p[10] * 255.f, 0.f), 255.f);
+      for (int c = 0; c < 3; ++c) {
+        float l = px[c];
+        if (p[9] != 1.f) l *= p[9];
+        if (p[10] != 0.f) l += p[10] * 255.f;
+        px[c] = floorf(fminf(fmaxf(l, 0.f), 255.f));
+      }
+    }
     if (((int)p[16]) & 1) {
-      float h, s, v;
-      bgr2hsv(px[0], px[1], px[2], h, s, v);
-      h = fmodf(h + p[13] + 360.f, 180.f);
-      s = fminf(fmaxf(s + p[14], 0.f), 255.f);
-      v = fminf(fmaxf(v + p[15], 0.f), 255.f);
-      hsv2bgr(h, s, v, px[0], px[1], px[2]);
+      int h, sa, v, r8, g8, b8;
+      rgb2hsv_u8((int)px[0], (int)px[1], (int)px[2], h, sa, v);     // channel 0 is albumentations' "R" (see above)
+      // LUTs of _shift_hsv_uint8: (arange(256, int16) + shift) mod 180 / clipped, cast to uint8: the shifts are Python floats, the
+      // float sum is truncated by the cast
+      const float hs = p[13], ss = p[14], vs = p[15];
+      if (hs != 0.f) { float t = fmodf((float)h + hs, 180.f); if (t < 0.f) t += 180.f; h = (int)t; }   // np.mod: result has the divisor's sign
+      if (ss != 0.f) sa = (int)fminf(fmaxf((float)sa + ss, 0.f), 255.f);
+      if (vs != 0.f) v = (int)fminf(fmaxf((float)v + vs, 0.f), 255.f);
+      hsv2rgb_u8(h, sa, v, r8, g8, b8);
+      px[0] = (float)r8; px[1] = (float)g8; px[2] = (float)b8;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) img_out[((size_t)n * 3 + c) * H * W + (size_t)y * W + x] = rintf(fminf(fmaxf(px[c], 0.f), 255.f));
+    for (int c = 0; c < 3; ++c) img_out[((size_t)n * 3 + c) * H * W + (size_t)y * W + x] = px[c];
     // ---- mask: nearest, 0 outside
     const int mx = (int)floorf(sx + 0.5f), my = (int)floorf(sy + 0.5f);
     const bool inside = in_crop && mx >= 0 && mx < W && my >= 0 && my < H;

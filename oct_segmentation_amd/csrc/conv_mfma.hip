@@ -1039,6 +1039,7 @@ static Choice choose(const ConvArgs& a, int esz) {
       const long long b16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) * ((a.Cout + BN - 1) / BN);
       const long long b8 = (long long)a.N * ((a.OH + 7) / 8) * ((a.OW + TW - 1) / TW) * ((a.Cout + BN - 1) / BN);
       if (b16 <= 256 && b8 > 256) wm_first = 4;
+      // (tried in round 2: 8x16 tiles for the 1.1-round case of ResNet layer3, 288 -> 576 workgroups: 87 -> 93 us per layer, not kept)
     }
   }
   static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch

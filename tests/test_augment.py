@@ -99,28 +99,97 @@ def test_warp_matches_a_torch_bilinear_gather_and_masks_stay_binary(cuda):
         assert (out[n] - ref).abs().max().item() <= 0.5 + 0.3
 
 
+def test_oracle_hsv_8bit_known_answers():
+    """The numpy restatement of OpenCV's 8-bit RGB<->HSV (oracle/augment_ref.py) on colours whose HSV is documented: H in half
+    degrees [0, 180), S and V in [0, 255]; greys have S = 0 and round-trip exactly; saturated primaries round-trip exactly."""
+    from oracle.augment_ref import hsv2rgb_u8, rgb2hsv_u8, shift_hsv_uint8
+    rgb = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255], [128, 128, 128], [0, 0, 0], [255, 255, 255],
+                    [200, 100, 50]], dtype=np.uint8)
+    hsv = rgb2hsv_u8(rgb)
+    want = np.array([[0, 255, 255], [60, 255, 255], [120, 255, 255], [30, 255, 255], [90, 255, 255], [150, 255, 255], [0, 0, 128], [0, 0, 0], [0, 0, 255],
+                     [10, 191, 200]], dtype=np.uint8)
+    assert np.array_equal(hsv, want)
+    assert np.array_equal(hsv2rgb_u8(hsv[:9]), rgb[:9])
+    assert np.abs(hsv2rgb_u8(hsv[9:]).astype(int) - rgb[9:].astype(int)).max() <= 2      # H is quantised to 2 degrees
+    # a hue shift of +60 (half-degree units) turns red into blue... in the frame albumentations believes to be RGB
+    assert np.array_equal(shift_hsv_uint8(rgb[:1], 60, 0, 0), rgb[1:2])
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    assert np.array_equal(shift_hsv_uint8(x, 0, 0, 0), hsv2rgb_u8(rgb2hsv_u8(x)))
+    assert np.abs(hsv2rgb_u8(rgb2hsv_u8(x)).astype(int) - x.astype(int)).max() <= 6        # the 8-bit round trip is lossy by design
+
+
 @pytest.mark.gpu
-def test_photometric_ops(cuda):
+def test_photometric_ops_match_the_uint8_chain(cuda):
+    """GaussNoise / RandomBrightnessContrast / HueSaturationValue of the kernel against the oracle's restatement of the reference's
+    uint8 stages (albumentations 1.4.3 over OpenCV 8-bit HSV; oracle/augment_ref.py): brightness-contrast and every hue / saturation /
+    value shift within one grey level (float vs the fixed-point reciprocal tables), noise by its statistics."""
+    from oracle.augment_ref import brightness_contrast_uint8, shift_hsv_uint8
     S = 64
-    img, mask = _frames(4, 1, S, seed=3)
-    p = np.stack([A.pack_params(np.eye(3), alpha=1.12, beta=-0.08),
-                  A.pack_params(np.eye(3), sigma=2.0, seed=4242),
-                  A.pack_params(np.eye(3), hue=0.0, sat=0.0, val=0.0, hsv_on=True),
-                  A.pack_params(np.eye(3), hue=10.0, sat=-15.0, val=12.0, hsv_on=True)])
-    out, _ = A.augment(img.to(cuda), mask.to(cuda), p)
+    img, mask = _frames(8, 1, S, seed=3)
+    rng = np.random.default_rng(4)
+    shifts = [(0.0, 0.0, 0.0), (10.0, -15.0, 12.0), (-14.3, 19.6, -7.2), (3.7, 0.0, 0.0), (0.0, -20.0, 0.0), (0.0, 0.0, 15.0)]
+    rows = [A.pack_params(np.eye(3), alpha=1.12, beta=-0.08), A.pack_params(np.eye(3), sigma=2.0, seed=4242)]
+    rows += [A.pack_params(np.eye(3), hue=h, sat=s_, val=v, hsv_on=True) for h, s_, v in shifts]
+    out, _ = A.augment(img.to(cuda), mask.to(cuda), np.stack(rows))
     out = out.cpu()
-    want = (img[0] * 1.12 - 0.08 * 255).clamp(0, 255).round()                  # RandomBrightnessContrast, brightness_by_max
-    assert (out[0] - want).abs().max().item() <= 1.0 and ((out[0] - want).abs() > 0).float().mean().item() < 0.02
-    d = (out[1] - img[1]).flatten()                                            # GaussNoise: N(0, sigma^2), rounded, clipped
+    hwc = lambda t: t.permute(1, 2, 0).numpy().astype(np.uint8)     # noqa: E731  (channel 0 = B of the reference's BGR frame)
+    want = brightness_contrast_uint8(hwc(img[0]), 1.12, -0.08)
+    assert np.abs(hwc(out[0]).astype(int) - want.astype(int)).max() <= 1
+    assert (hwc(out[0]) != want).mean() < 0.01
+    d = (out[1] - img[1]).flatten()                                 # GaussNoise: N(0, sigma^2) added, clipped, TRUNCATED (mean -0.5)
     inner = (img[1].flatten() > 8) & (img[1].flatten() < 247)
-    assert abs(d[inner].mean().item()) < 0.05 and abs(d[inner].std().item() - 2.0) < 0.1
-    assert (out[2] - img[2]).abs().max().item() <= 1.0                         # HSV round trip is the identity up to rounding
-    b, g, r = out[3][0], out[3][1], out[3][2]                                  # a value shift of +12 raises max(B,G,R) by 12
-    v_in = img[3].max(dim=0).values
-    v_out = torch.stack([b, g, r]).max(dim=0).values
-    ok = v_in < 240
-    assert (v_out[ok] - (v_in[ok] + 12)).abs().max().item() <= 1.0
+    assert abs(d[inner].mean().item() + 0.5) < 0.06 and abs(d[inner].std().item() - (4.0 + 1.0 / 12) ** 0.5) < 0.1
+    for k, (h, s_, v) in enumerate(shifts):
+        got = hwc(out[2 + k])
+        ref = shift_hsv_uint8(hwc(img[2 + k]), h, s_, v)
+        diff = np.abs(got.astype(int) - ref.astype(int))
+        assert diff.max() <= 1, (h, s_, v, diff.max())
+        assert (diff > 0).mean() < 0.02, (h, s_, v, (diff > 0).mean())
     assert out.min().item() >= 0 and out.max().item() <= 255 and torch.equal(out, out.round())
+    _ = rng
+
+
+@pytest.mark.gpu
+def test_distribution_against_the_sequential_uint8_chain(cuda):
+    """The kernel's single resampling against the oracle's restatement of the reference's SEQUENTIAL chain (every stage its own uint8
+    image): the same per-frame decisions (sample_frame), 400 OCT-shaped frames.  Frames without a resampled stage must agree
+    to one grey level (flip, crop + pad, brightness-contrast, HSV); over all frames the per-channel mean and standard deviation
+    agree within 1 % and the masks within 1 % of their area."""
+    from oracle.augment_ref import apply_chain
+    from synth import make_batch
+    S, N = 64, 400
+    rng = np.random.default_rng(2024)
+    img, mask = make_batch(N, 2, S, seed=77)
+    rows, logs = [], []
+    for _ in range(N):
+        M, post, rect, alpha, beta, sigma, seed, hue, sat, val, hsv_on, log = A.sample_frame(S, rng)
+        rows.append(A.pack_params(M, alpha, beta, sigma, seed, hue, sat, val, hsv_on, post, rect)); logs.append(log)
+    out, mout = A.augment(img.to(cuda), mask.to(cuda), np.stack(rows))
+    out, mout = out.cpu().numpy(), mout.cpu().numpy()
+    noise_rng = np.random.default_rng(5)
+    ref_i, ref_m = np.empty_like(out), np.empty_like(mout)
+    exact = 0
+    for n in range(N):
+        i8 = img[n].permute(1, 2, 0).numpy().astype(np.uint8)
+        m8 = mask[n].permute(1, 2, 0).numpy().astype(np.uint8)
+        g = noise_rng.normal(0.0, logs[n]['noise'], size=(S, S, 3)) if 'noise' in logs[n] else None
+        ri, rm = apply_chain(i8, m8, logs[n], S, g)
+        ref_i[n], ref_m[n] = ri.transpose(2, 0, 1), rm.transpose(2, 0, 1)
+        if not ({'ssr', 'perspective', 'noise'} & set(logs[n])):
+            assert np.abs(out[n] - ref_i[n]).max() <= 1.0, logs[n]
+            assert np.array_equal(mout[n], ref_m[n].astype(np.float32)), logs[n]
+            exact += 1
+    assert exact > N // 3
+    for c in range(3):
+        a, b = out[:, c].astype(np.float64), ref_i[:, c].astype(np.float64)
+        assert abs(a.mean() - b.mean()) <= 0.01 * b.mean() + 0.05, (c, a.mean(), b.mean())
+        assert abs(a.std() - b.std()) <= 0.01 * b.std() + 0.05, (c, a.std(), b.std())
+    assert abs(mout.mean() - ref_m.mean()) <= 0.01 * ref_m.mean()
+    # per frame, the resampled stages differ by interpolation only
+    per_frame = np.abs(out - ref_i).mean(axis=(1, 2, 3))
+    noisy = np.array(['noise' in l for l in logs])
+    assert per_frame[~noisy].max() < 3.0 and np.median(per_frame[~noisy]) < 0.5
 
 
 @pytest.mark.gpu
