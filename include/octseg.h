@@ -176,6 +176,11 @@ int octseg_optim_step(int kind, float* params, const float* grads, float* state_
                       size_t numel, float lr, float weight_decay, int step, float grad_scale,
                       void* stream);
 
+/* Deterministic-reduction mode (also OCTSEG_DETERMINISTIC=1 in the environment): weight gradients without split-K atomics, Dice sums and
+ * bias gradients by one workgroup per output -- two runs of the same step give bit-identical losses and gradients (the default mode
+ * orders its floating-point atomics by arrival).  Slower; for tests and debugging (torch.use_deterministic_algorithms' counterpart). */
+int octseg_set_deterministic(int on);
+
 /* diagnostic hook: with a library built with -DOCTSEG_STAMP, octseg_conv2d_forward adds per-phase cycle
  * sums of the tap loop into dev_buf[6] (u64, device); a no-op in the shipped build. */
 int octseg_debug_set_stamp(unsigned long long* dev_buf);

@@ -67,6 +67,7 @@ SYMBOLS = {
     'octseg_conv2d_backward_weight': (C.c_int, [C.c_int, _P, _P, _P] + [C.c_int] * 10 + [_P]),
 }
 
+SYMBOLS['octseg_set_deterministic'] = (C.c_int, [C.c_int])
 SLICE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t)
 SYMBOLS['octseg_net_backward_sliced'] = (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P, SLICE_CB, _P])
 

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const void* g, size_t 
 }
 hipError_t launch_channel_sum(int dtype, const void* g, size_t npix, int Cstride, int C, float* out, hipStream_t st) {
   OCTSEG_NO_F16(dtype);
-  const int gr = grid_for(npix, 256, 512);
+  const int gr = deterministic_mode() ? 1 : grid_for(npix, 256, 512);
   if (dtype == DT_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
   else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, g, npix, Cstride, C, out);
   return hipGetLastError();
@@ -732,6 +732,7 @@ hipError_t launch_dice_fwd(const DiceArgs& a, hipStream_t st) {
   // 32 elements per thread: a workgroup ends in six block reductions and six atomics, which dominated at 8 per thread
   int chunks = (int)((a.HW + 256 * 32 - 1) / (256 * 32));
   if (chunks > 128) chunks = 128;
+  if (deterministic_mode()) chunks = 1;   // one workgroup per (image, class): its three sums meet zeroed replicas, no ordering left to chance
   hipLaunchKernelGGL(dice_fwd_kernel, dim3(chunks, a.C, a.B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();

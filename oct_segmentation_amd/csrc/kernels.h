@@ -23,6 +23,10 @@ bool gemm1x1_eligible(const ConvArgs& a, int dtype);
 int gemm1x1_rows(const ConvArgs& a);
 hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t st);
 
+// Deterministic-reduction mode (octseg_set_deterministic / OCTSEG_DETERMINISTIC=1): no floating-point atomic meets another
+// workgroup's -- weight gradients without split-K, Dice sums and bias gradients by one workgroup per output.  Slower; bit-stable.
+bool deterministic_mode();
+
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 

@@ -1401,3 +1401,10 @@ int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, floa
 }  // extern "C"
 
 static bool serial_mode() { return g_serial; }
+
+static int g_deterministic = -1;   // -1: not decided yet (environment)
+bool octseg::deterministic_mode() {
+  if (g_deterministic < 0) g_deterministic = getenv("OCTSEG_DETERMINISTIC") != nullptr ? 1 : 0;
+  return g_deterministic != 0;
+}
+extern "C" int octseg_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return OCTSEG_OK; }

@@ -474,6 +474,7 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   int ks = 512 / (gx * gy);  // one resident round at most (two workgroup slots per CU): 516 workgroups take twice as long as 504
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
+  if (deterministic_mode()) ks = 1;   // every dW element then has ONE writer (its atomicAdd meets a zeroed buffer): a fixed summation order
   a.ksplit = ks;
   static bool attr_set = false;
   if (!attr_set) {

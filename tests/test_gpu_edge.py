@@ -235,3 +235,31 @@ def test_encoder_weights_and_smp_kwargs(cuda, tmp_path):
     with pytest.raises(TypeError):
         SegNet('unet', 'resnet18', device=cuda, not_an_smp_option=1)
     SegNet('unet', 'resnet18', device=cuda, decoder_use_batchnorm=True, encoder_depth=5, decoder_channels=[256, 128, 64, 32, 16])
+
+
+@pytest.mark.parametrize('arch,enc', [('unetplusplus', 'resnet34'), ('linknet', 'resnet50')])
+def test_deterministic_mode_gives_bit_identical_steps(cuda, arch, enc):
+    """octseg_set_deterministic(1): the same step twice -> the same loss, logits, confusion counts, BN buffers and GRADIENT ARENA bit
+    for bit (no split-K / Dice / bias atomics racing), and it agrees with the default mode to rounding."""
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.engine import SegNet
+    net = SegNet(arch, enc, classes=2, device=cuda, compute_dtype=torch.float32, seed=6).train()
+    img, mask = (t.to(cuda) for t in make_batch(3, 2, 160, seed=8))
+    buf0 = net.bn_buffers.clone()
+
+    def run():
+        net.bn_buffers.copy_(buf0)
+        loss, logits, stats = net.train_step_raw(img, mask)
+        torch.cuda.synchronize()
+        return loss.clone(), logits.clone(), stats.clone(), net._grad_arena.clone(), net.bn_buffers.clone()
+    ref = run()
+    L.check(L.lib().octseg_set_deterministic(1))
+    try:
+        a, b = run(), run()
+    finally:
+        L.check(L.lib().octseg_set_deterministic(0))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[1], ref[1]) and torch.equal(a[2], ref[2])
+    scale = ref[3].abs().max().item()
+    assert (a[3] - ref[3]).abs().max().item() <= 1e-4 * scale and abs(a[0].item() - ref[0].item()) <= 1e-6   # another fp32 summation order
