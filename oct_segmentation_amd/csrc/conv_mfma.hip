@@ -60,6 +60,10 @@ constexpr bool ROWMAP_GROUPED = false;   // A/B build switch
 constexpr bool ROWMAP_GROUPED = true;
 #endif
 
+// M sub-tiles (2 rows x 16 pixels each) per wave: 2, or 4 in the wide-N configuration (NT = 4, 64-byte K chunks: four waves of
+// 128 pixels x 128 channels, one per SIMD with the whole register file -- 256 accumulators)
+static constexpr int wave_mt(int NT, int RB) { return (NT == 4 && RB == 64) ? 4 : 2; }
+
 struct TilePos { int n, y0, x0, co0, w_mt, nt_idx; };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
@@ -101,11 +105,11 @@ static __device__ __forceinline__ TilePos map_tile(const ConvArgs& a) {
 
 // Epilogue shared by the conv kernels: bias, BN partials, LDS transpose, 16-byte stores / accumulates.
 // All waves must be past their last LDS read of the main loop (barrier) when this is entered.
-template <typename T, int NT, int WN, int WM, bool GROUPED>
-static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* smem, f32x16_t (&acc)[2][NT], const TilePos& tp) {
+template <typename T, int NT, int WN, int WM, bool GROUPED, int MT>
+static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* smem, f32x16_t (&acc)[MT][NT], const TilePos& tp) {
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int BN = NT * 32 * WN;
-  constexpr int TH = 4 * WM;
+  constexpr int TH = 2 * MT * WM;
   constexpr int BM = TH * TW;
   constexpr int VEC = Tr<T>::VEC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,8 +134,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       //   plain row map:   row (i >> 3), column (i & 3) + 8 * ((i >> 2) & 1) + 4 * h
       //   grouped row map: row h ^ [(i >> 2) is 1 or 2], column 4 * (i >> 2) + (i & 3)      (RowMap<true>)
       const int lchan = (wn * NT * 32 + r) * ES;
-      const int lbase = GROUPED ? (wm * 4 * TW + h * TW) * OPITCH + lchan : (wm * 4 * TW + 4 * h) * OPITCH + lchan;
-      const int lbase_x = (wm * 4 * TW + (1 - h) * TW) * OPITCH + lchan;   // grouped: the other row of the strip
+      const int lbase = GROUPED ? (wm * 2 * MT * TW + h * TW) * OPITCH + lchan : (wm * 2 * MT * TW + 4 * h) * OPITCH + lchan;
+      const int lbase_x = (wm * 2 * MT * TW + (1 - h) * TW) * OPITCH + lchan;   // grouped: the other row of the strip
       (void)lbase_x;
       // transposed tile into LDS; the bias add and the BN partial sums only where the layer has them (uniform
       // branches: a dgrad has neither and saves three of its four vector instructions per element)
@@ -146,7 +150,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             bias = co < a.Cout ? a.bias[co] : 0.f;           // lanes past Cout: their sums are never stored
           }
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
+          for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               float val = acc[mt][nt][i];
@@ -289,11 +293,11 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     const bool cok = co < a.Cout;
     const float bias = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;   // A row of this accumulator element
-        const int ty = wm * 4 + mt * 2 + RowMap<GROUPED>::ty(rr), tx = RowMap<GROUPED>::tx(rr);
+        const int ty = wm * 2 * MT + mt * 2 + RowMap<GROUPED>::ty(rr), tx = RowMap<GROUPED>::tx(rr);
         const int gy = y0 + ty, gx = x0 + tx;
         float val = acc[mt][nt][i] + bias;
         if (a.relu_out) val = fmaxf(val, 0.f);
@@ -418,13 +422,14 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4 };
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
+__global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 2) ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
+  constexpr int MT = wave_mt(NT, RB);
   const int dbuf = mode & 1;
   constexpr bool resident = LOOP == LOOP_RESIDENT;   // single K chunk + small slabs: every tap's weights stay in LDS, no per-tap DMA / barrier
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTHREADS = 64 * WM * WN;
   constexpr int BN = NT * 32 * WN;
-  constexpr int TH = 4 * WM;
+  constexpr int TH = 2 * MT * WM;
   constexpr int KC = RB / (int)sizeof(T);
   constexpr int PITCH = ConvCfg<RB>::PITCH, KSTEPS = ConvCfg<RB>::KSTEPS, VPR = ConvCfg<RB>::VPR;
   constexpr int NWAVES = WM * WN;
@@ -457,22 +462,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   char* ldsA = smem;                                  // [1 or 2] windows
   char* ldsB = smem + (dbuf ? 2 : 1) * abytes;        // [2] weight slab ring ([3] in the run9 ring mode)
 
-  f32x16_t acc[2][NT];
+  f32x16_t acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
-  int abase[2], bbase[NT];
+  int abase[MT], bbase[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     // grouped row map: the 16 lanes one ds_read_b128 LDS cycle serves read 16 CONSECUTIVE pixels of one window row, whose
     // 144-byte pitch spreads them over all 16 sixteen-byte slots of the 256-byte LDS line for every tap shift and window
     // width (the plain map mixed lanes of both strip rows in one group: two 2-way conflicts per group at RW = 18, 30 % of
     // all LDS cycles of the 3x3 layers, profiles/r1_sq_counters_conv3x3_512_256_352.txt)
-    const int ty = wm * 4 + mt * 2 + RowMap<ROWMAP_GROUPED>::ty(r), tx = RowMap<ROWMAP_GROUPED>::tx(r);
+    const int ty = wm * 2 * MT + mt * 2 + RowMap<ROWMAP_GROUPED>::ty(r), tx = RowMap<ROWMAP_GROUPED>::tx(r);
     abase[mt] = ((ty * lstride) * RW + tx * lstride) * PITCH + h * 16;
   }
   int bswz[NT];  // XOR swizzle of the 16-byte chunk index inside a slab row (matches pack_weight_image)
@@ -529,10 +534,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   // MFMAs of one tap.  The LDS fragment reads run two k-steps ahead of the MFMAs that consume them
   // (three register sets): LDS latency under load is several hundred cycles, a k-step of MFMAs is ~128.
   auto mma_tap = [&](const char* awin, const char* bsl, int toff) {
-    uint4 af[3][2], bf[3][NT];
+    constexpr int NFB = KSTEPS >= 3 ? 3 : KSTEPS;   // fragment register sets (a 64-byte K chunk has two k-steps: both fit up front)
+    uint4 af[NFB][MT], bf[NFB][NT];
     auto frag_load = [&](int buf, int ks) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+      for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
     };
@@ -540,14 +546,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     if (KSTEPS > 1) frag_load(1, 1);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+      if (ks + 2 < KSTEPS) frag_load((ks + 2) % NFB, ks + 2);
       // pin the stage order: left alone, hipcc sinks every read next to its MFMA (lgkmcnt(1) in front of
       // almost every MFMA pair) and the LDS latency is paid k-step by k-step
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % NFB][mt], bf[ks % NFB][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -556,10 +562,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
   // issued execute while the wave runs the filler, instead of every wave leaving the pipe idle in a common
   // issue / store phase at the end of the tap
   auto mma_tap_f = [&](const char* awin, const char* bsl, int toff, auto&& f0, auto&& f1, auto&& f2) __attribute__((always_inline)) {
-    uint4 af[3][2], bf[3][NT];
+    constexpr int NFB = KSTEPS >= 3 ? 3 : KSTEPS;   // fragment register sets (a 64-byte K chunk has two k-steps: both fit up front)
+    uint4 af[NFB][MT], bf[NFB][NT];
     auto frag_load = [&](int buf, int ks) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+      for (int mt = 0; mt < MT; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz[nt]) * 16));
     };
@@ -567,16 +574,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     if (KSTEPS > 1) frag_load(1, 1);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+      if (ks + 2 < KSTEPS) frag_load((ks + 2) % NFB, ks + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % NFB][mt], bf[ks % NFB][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
       if (ks == 0) f0();
       if (ks == 1) f1();
-      if (ks == 2) f2();
+      if (ks == 2 || (KSTEPS == 2 && ks == 1)) f2();   // (64-byte K chunks have two k-steps: the last filler follows the second)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -933,7 +940,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
       tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
     }
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
-    if constexpr (NDMA % NWAVES == 0 && RB == 128) run9r();
+    if constexpr (NDMA % NWAVES == 0 && (RB == 128 || (RB == 64 && NT == 4))) run9r();
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
     run1p();   // (the rolled loop is not kept as an A/B switch here: with both in one function hipcc moved the by-value ConvArgs to scratch)
   } else {
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_mfm
     for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
 #endif
 
-  conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED>(a, smem, acc, tp);
+  conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED, MT>(a, smem, acc, tp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -955,7 +962,7 @@ namespace {
 struct Variant { int NT, WN, WM, RB; };
 
 size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* npass_out) {
-  const int TH = 4 * v.WM, BN = v.NT * 32 * v.WN, BM = TH * TW, PITCH = v.RB + 16;
+  const int TH = 2 * wave_mt(v.NT, v.RB) * v.WM, BN = v.NT * 32 * v.WN, BM = TH * TW, PITCH = v.RB + 16;
   (void)PITCH;
   const bool single = a.ntaps == 1;
   const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
@@ -973,7 +980,7 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 hipError_t launch_loop(const ConvArgs& a, int mode, size_t lds, hipStream_t st) {
-  constexpr int BN = NT * 32 * WN, TH = 4 * WM;
+  constexpr int BN = NT * 32 * WN, TH = 2 * wave_mt(NT, RB) * WM;
   const int mtiles = a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
   dim3 grid(mtiles, (a.Cout + BN - 1) / BN);
   static bool attr_set = false;
@@ -993,7 +1000,7 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
     case LOOP_RESIDENT: return launch_loop<T, NT, WN, WM, RB, LOOP_RESIDENT>(a, mode, lds, st);
     case LOOP_1X1: return launch_loop<T, NT, WN, WM, RB, LOOP_1X1>(a, mode, lds, st);
     case LOOP_RUN9:
-      if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9>(a, mode, lds, st);
+      if constexpr ((RB == 128 || (RB == 64 && NT == 4)) && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9>(a, mode, lds, st);
       else return hipErrorInvalidValue;
     case LOOP_RUN9S:
       if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9S>(a, mode, lds, st);
@@ -1009,6 +1016,33 @@ struct Choice { Variant v; int dbuf; size_t lds; int resident; int ring3; int ri
 static Choice choose(const ConvArgs& a, int esz) {
   Choice c;
   c.ring3 = 0; c.ring1 = 0;
+  // Wide-N configuration for the 3x3 layers with >= 256 output channels (54 % of U-Net++/resnet101's FLOPs: x_1_2, x_2_2, x_1_1,
+  // x_0_0 and the data gradients of the wide concat layers): 16x16 pixels x 256 channels per workgroup, 4 waves of 128 pixels x
+  // 128 channels (256 accumulators each: one wave per SIMD owns the whole register file), 64-byte K chunks.  Against the 128-channel tile the staged window serves twice the
+  // output channels -- half the activation loads, lazy-BN arithmetic and LDS stores per MFMA, the input read once instead of
+  // once per N tile -- and a wave reads 8 fragments per 16 MFMAs instead of 4 per 4.  LDS: 2 x 30 KiB windows + 3 x 16 KiB slabs.
+  {
+    static const bool off = getenv("OCTSEG_NO_N256") != nullptr;   // A/B switch
+    const int n256 = (a.Cout + 255) / 256;
+    const int kc = 64 / esz;
+    // Measured per layer (U-Net++/resnet101, 16 x 704^2, profiles/r2_layers_alone.csv): 1024 -> 256 @176^2 forward 2252 -> 2072 us
+    // (1129 TFLOP/s), 256 -> 256 @176^2 forward 725 -> 622; but 1536 -> 512 @88^2 +12 % and every wide data gradient (K = 64..512,
+    // N = 768..3072) +3..14 % slower: one wave per SIMD has nobody to cover the fragment reads at the head of a tap, and the
+    // 88^2 grids lose a round.  So: exactly 256 output channels, K >= 256, a grid of >= 1024 workgroups.
+    const bool fits = a.Cout == 256 && a.Cin >= 256 && (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) >= 1024;
+    static const bool all = getenv("OCTSEG_N256_ALL") != nullptr;   // experiments: every >= 256-channel 3x3 layer
+    if (!off && (fits || all) && a.ntaps == 9 && a.istride == 1 && a.Cout > 128 && (n256 * 256 - a.Cout) * 10 <= a.Cout && a.Cin > kc) {
+      const Variant v{4, 2, 2, 64};   // 2 x 2 waves of (4 M sub-tiles x 4 N sub-tiles)
+      int npass = 0;
+      const size_t lds = variant_lds(a, v, esz, 1, &npass);
+      const size_t slab = (size_t)256 * 64;
+      const long long wgs = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) * n256;
+      if (wgs >= 384 && npass <= 8 && lds + slab <= (size_t)160 * 1024) {
+        c.v = v; c.dbuf = 1; c.lds = lds + slab; c.resident = 0; c.ring3 = 1;
+        return c;
+      }
+    }
+  }
   int NT, WN;
   if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
   const int kc128 = 128 / esz;
@@ -1102,6 +1136,7 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
     return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, loop, c.lds, st);
+  OCTSEG_CASE(4, 2, 2, 64)
   OCTSEG_CASE(2, 2, 4, 128)
   OCTSEG_CASE(2, 2, 2, 128)
   OCTSEG_CASE(1, 2, 4, 128)
@@ -1133,7 +1168,7 @@ ConvPackInfo conv_pack_info(const ConvArgs& a, int dtype) {
 
 int conv_num_mtiles(const ConvArgs& a, int dtype) {
   const Choice c = choose(a, (int)dtype_size(dtype));
-  const int TH = 4 * c.v.WM;
+  const int TH = 2 * wave_mt(c.v.NT, c.v.RB) * c.v.WM;
   return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
 }
 
