@@ -471,7 +471,14 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && std33 && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
-  int ks = 512 / (gx * gy);  // one resident round at most (two workgroup slots per CU): 516 workgroups take twice as long as 504
+  // One resident round at most (two workgroup slots per CU: 516 workgroups take twice as long as 504).  Every workgroup ends by
+  // adding its 64 x 64 x taps fp32 tile to dW with atomics: 504 x 147 KiB = 74 MB of atomic traffic per 3x3 layer, which is what
+  // bounds the encoder's 3x3 weight gradients (small maps, 256..512 channels) -- half the workgroups (one per CU, twice the
+  // pixels each) halve it: encoder 3x3 wgrad 3.89 -> 2.98 ms per step, decoder 14.7 -> 14.4.  1x1 layers flush 16 KiB tiles and want
+  // the occupancy: 512 there (256 measured 2.7 -> 3.7 ms).
+  static const int wg_env = getenv("OCTSEG_WGRAD_WGS") ? atoi(getenv("OCTSEG_WGRAD_WGS")) : 0;   // experiments
+  const int wg_target = wg_env > 0 ? wg_env : (NTAPS == 1 ? 512 : 256);
+  int ks = wg_target / (gx * gy);
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
   if (deterministic_mode()) ks = 1;   // every dW element then has ONE writer (its atomicAdd meets a zeroed buffer): a fixed summation order

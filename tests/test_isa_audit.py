@@ -15,7 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
 def test_no_instruction_touches_an_asm_load_destination_in_flight():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'audit_asm_loads.py')], capture_output=True, text=True, timeout=900)
+    # the build (make -C oct_segmentation_amd/csrc, i.e. __graft_entry__.build()) leaves the ISA it audited next to the objects: reuse it
+    # when it is newer than every source it was generated from, regenerate it otherwise (4 minutes of hipcc)
+    csrc = os.path.join(ROOT, 'oct_segmentation_amd', 'csrc')
+    isa = os.path.join(csrc, 'build', 'conv_mfma.s')
+    deps = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'common.h', 'conv_common.h', 'kernels.h')]
+    args = [isa] if os.path.exists(isa) and all(os.path.getmtime(isa) >= os.path.getmtime(d) for d in deps) else []
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'audit_asm_loads.py')] + args, capture_output=True, text=True, timeout=1500)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
     assert r.returncode == 0, tail
     n = int(tail.split()[0])
