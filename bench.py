@@ -13,7 +13,7 @@ src/models/smp/train.py:122-133); per-GPU batch stays 16, so scaling is "weak" (
 keeps the global batch at 16 instead: 16/N frames per GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline      -- the MFMA conv kernels (conv_mfma_kernel + wgrad_mfma_kernel), timed live with HIP
+  roofline      -- the MFMA conv kernels (conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel), timed live with HIP
                    events on the launch stream: algorithmic conv FLOPs (6 * MACs * frames, SURVEY.md
                    section 8d) / summed kernel time, vs 2.5 PFLOP/s dense bf16.  `achieved` comes from an
                    untimed extra pass with every launch on one stream (kernels alone); the brackets of the
@@ -357,7 +357,7 @@ def main():
                        'global_batch': global_batch, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
             'loss': round(loss_val, 6),
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),

@@ -86,6 +86,63 @@ class _DiceStep(torch.autograd.Function):
         return g * gloss, None, None, None, None, None, None
 
 
+class _LayerRef:
+    """One module position of the reference's tree (``model.model.encoder.layer4[-1]``, the Grad-CAM target of
+    ``src/models/visualize_activation_maps.py:103``).  The engine has no per-layer ``nn.Module`` objects -- the whole graph runs
+    behind ``octseg_net_forward`` -- so this is a named handle: it knows its ``state_dict`` prefix and its parameter views, and it
+    refuses forward hooks loudly instead of letting a CAM tool record nothing."""
+
+    def __init__(self, net, name):
+        self._net, self.name = net, name
+
+    def named_parameters(self):
+        pre = self.name + '.'
+        return [(p['name'][len(pre):], self._net._torch_view(p)) for p in self._net.param_table if p['name'].startswith(pre)]
+
+    def register_forward_hook(self, *_a, **_k):
+        raise NotImplementedError(f'{self.name}: the gfx950 engine exposes no per-layer activations to hooks (Grad-CAM tooling is '
+                                  f'outside the accelerated path); use engine.debug_tensor() for a conv output')
+    register_full_backward_hook = register_forward_hook
+
+    def __repr__(self):
+        return f'<octseg layer {self.name}>'
+
+
+class _TreeRef:
+    """Attribute / index navigation over the parameter names: ``.encoder.layer4[-1].conv3``."""
+
+    def __init__(self, net, prefix):
+        self._net, self._prefix = net, prefix
+
+    def _children(self):
+        pre = self._prefix + '.'
+        return sorted({p['name'][len(pre):].split('.')[0] for p in self._net.param_table if p['name'].startswith(pre)},
+                      key=lambda k: (0, int(k)) if k.isdigit() else (1, k))
+
+    def __getattr__(self, key):
+        if key.startswith('_'):
+            raise AttributeError(key)
+        if key not in self._children():
+            raise AttributeError(f'{self._prefix} has no submodule {key!r} (has: {self._children()})')
+        return _TreeRef(self._net, f'{self._prefix}.{key}')
+
+    def __len__(self):
+        return len([k for k in self._children() if k.isdigit()])
+
+    def __getitem__(self, i):
+        idx = [k for k in self._children() if k.isdigit()]
+        return _TreeRef(self._net, f'{self._prefix}.{idx[i]}')
+
+    def ref(self):
+        return _LayerRef(self._net, self._prefix)
+
+    def register_forward_hook(self, *a, **k):
+        return self.ref().register_forward_hook(*a, **k)
+
+    def __repr__(self):
+        return f'<octseg module path {self._prefix}: {self._children()}>'
+
+
 class SegNet(nn.Module):
     """Segmentation network living in ``liboctseg_hip.so``.
 
@@ -146,6 +203,19 @@ class SegNet(nn.Module):
         self._by_name = {p['name']: p for p in self.param_table}
         self.initialize(seed)
         self.load_encoder_weights(encoder_weights)
+
+    # the reference's attribute paths (``model.model.encoder.layer4[-1]``): name handles, see _TreeRef
+    @property
+    def encoder(self):
+        return _TreeRef(self, 'encoder')
+
+    @property
+    def decoder(self):
+        return _TreeRef(self, 'decoder')
+
+    @property
+    def segmentation_head(self):
+        return _TreeRef(self, 'segmentation_head')
 
     def load_encoder_weights(self, encoder_weights):
         """``encoder_weights`` of smp.create_model.  The reference never passes it, so smp's default ``'imagenet'`` downloads

@@ -263,3 +263,19 @@ def test_deterministic_mode_gives_bit_identical_steps(cuda, arch, enc):
     assert torch.equal(a[1], ref[1]) and torch.equal(a[2], ref[2])
     scale = ref[3].abs().max().item()
     assert (a[3] - ref[3]).abs().max().item() <= 1e-4 * scale and abs(a[0].item() - ref[0].item()) <= 1e-6   # another fp32 summation order
+
+
+def test_reference_attribute_paths(cuda):
+    """``model.model.encoder.layer4[-1]`` exists (reference src/models/visualize_activation_maps.py:103) as a named handle; hooks are
+    refused loudly rather than silently recording nothing."""
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    m = OCTSegmentationModel('unet', 'resnet50', 'x', 3, ['Lumen'], device=cuda, compute_dtype=torch.float32, seed=1)
+    last = m.model.encoder.layer4[-1]
+    assert len(m.model.encoder.layer4) == 3 and repr(last).endswith("['bn1', 'bn2', 'bn3', 'conv1', 'conv2', 'conv3']>")
+    w = dict(last.ref().named_parameters())['conv3.weight']
+    assert tuple(w.shape) == (2048, 512, 1, 1) and torch.equal(w, m.model.state_dict()['encoder.layer4.2.conv3.weight'])
+    assert len(m.model.decoder.blocks) == 5
+    with pytest.raises(NotImplementedError, match='no per-layer activations'):
+        last.register_forward_hook(lambda *a: None)
+    with pytest.raises(AttributeError):
+        m.model.encoder.layer5

@@ -11,4 +11,9 @@ OCTSEG_NO_SIDE_STREAM=1 OCTSEG_NO_FWD_LANES=1 rocprofv3 --kernel-trace --stats -
 python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_serial/*/*.db | head -1) gpurun_out/${tag}_serial_kernel_stats.csv > gpurun_out/prof_${tag}_serial.txt
 python3 tools/collect_traffic.py ${tag} > gpurun_out/${tag}_traffic.log 2>&1
 rm -rf gpurun_out/prof_${tag}_w gpurun_out/prof_${tag}_serial gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
+OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_alone.csv python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python3 tools/group_layers.py gpurun_out/${tag}_layers_alone.csv 2 > gpurun_out/${tag}_layer_groups.txt
+python3 bench.py --workload ensemble_704_fp16 --steps 30 > gpurun_out/${tag}_ensemble_b1.json 2> /dev/null
+python3 bench.py --workload ensemble_704_fp16 --steps 20 --batch 8 > gpurun_out/${tag}_ensemble_b8.json 2> /dev/null
+for w in linknet_r50_704 unet_r50_704; do python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> /dev/null; done
 tail -c 600 gpurun_out/${tag}_bench_default.err
