@@ -28,7 +28,6 @@
 #include <type_traits>
 
 namespace octseg {
-namespace {
 
 constexpr int G1_BM = 128;     // pixel rows per item: 4 waves x 32
 constexpr int G1_D = 3;        // K steps of activations in flight per wave
@@ -44,8 +43,16 @@ struct G1Args {
   const float* bias; int relu_out;       // eval with folded BatchNorm: y = relu?(acc + bias[n])
 };
 
-template <typename T, int NT, bool AFF>
-__global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
+// BRES: the whole K x BN weight panel of the workgroup's N tile stays in LDS (K <= 256: four slabs, 64 KiB) for all of its M tiles --
+// no per-step weight traffic, NO barrier in the main loop (waves run free: one's epilogue overlaps the others' loads and
+// MFMAs), one workgroup per CU with the whole register file, six K steps of activations in flight per wave.  For the
+// output-heavy layers (N >= 4 tiles: bottleneck conv3, the data gradient of conv1), whose items are only K / 64 <= 4 steps long.
+// NEGATIVE RESULT (round 2), kept opt-in: see g1_geom.
+template <typename T, int NT, bool AFF, bool BRES>
+__global__ __launch_bounds__(256, BRES ? 1 : 2) void gemm1x1_kernel(const G1Args a) {
+  constexpr int D = BRES ? 6 : G1_D;            // K steps of activations in flight per wave
+  constexpr int NSET = D + 1;                   // register sets of the activation ring
+  constexpr int NSLOT = BRES ? 4 : 2;           // weight slabs in LDS
   constexpr int BN = NT * 32;
   constexpr int SLAB = BN * 128;                 // bytes of one (K step, N tile) weight slab
   constexpr int NPB = SLAB / 4096;               // 16-byte pieces of the slab per thread (1, 2 or 4)
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
   constexpr int RPI = 64 / PPR;                  // rows stored per wave instruction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsB = smem;                                           // [2][SLAB]
-  char* strip0 = smem + 2 * SLAB;                              // [4 waves][32][OPITCH]
+  char* strip0 = smem + NSLOT * SLAB;                          // [4 waves][32][OPITCH]
   float* lds_ss = (float*)(strip0 + 4 * 32 * OPITCH);          // AFF: scale[K], shift[K]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
     return a.x + (long long)row * a.xstride + 64 * h;
   };
   const char* pf_ptr = row_ptr(pf_mt);
-  uint4 A[G1_D + 1][4];
+  uint4 A[NSET][4];
   auto load_A = [&](uint4 (&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dst[j] = *(const uint4*)(pf_ptr + 16 * j);
@@ -131,12 +138,16 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
   const int bbase = r * 128;
   const unsigned floor16 = a.relu ? 0u : 0x80008000u;
 
-  // ---- prologue: slab 0 into slot 0, slab 1 in registers, G1_D activation steps in flight
-  G1_LOAD_B();
-  G1_STORE_B(0);
-  G1_LOAD_B();
+  // ---- prologue: slab 0 into slot 0, slab 1 in registers (BRES: every slab of the panel into its slot), D activation steps in flight
+  if constexpr (BRES) {
+    for (int q = 0; q < S; ++q) { G1_LOAD_B(); G1_STORE_B(q); }
+  } else {
+    G1_LOAD_B();
+    G1_STORE_B(0);
+    G1_LOAD_B();
+  }
 #pragma unroll
-  for (int d = 0; d < G1_D; ++d) load_A(A[d]);
+  for (int d = 0; d < D; ++d) load_A(A[d]);
   __syncthreads();
 
   int s = 0, mt = wg_m;
@@ -202,12 +213,14 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
 
   auto step = [&](auto set_c, int g) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
-    const int slot = g & 1;
-    // weights of step g + 1 (in registers since the previous step) into the other slot, then fetch those of step g + 2
-    G1_STORE_B(slot ^ 1);
-    G1_LOAD_B();
+    const int slot = BRES ? s : (g & 1);
+    if constexpr (!BRES) {
+      // weights of step g + 1 (in registers since the previous step) into the other slot, then fetch those of step g + 2
+      G1_STORE_B(slot ^ 1);
+      G1_LOAD_B();
+    }
     // activations of step g + D
-    load_A(A[(SET + G1_D) & 3]);
+    load_A(A[(SET + D) % NSET]);
     const bool tail = (mt * G1_BM + G1_BM > a.M);
     const bool valid = mt * G1_BM + wave * 32 + r < a.M;
     const char* bsl = ldsB + slot * SLAB + bbase;
@@ -241,15 +254,21 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
       s = 0;
       mt += Gm;
     }
-    __syncthreads();
+    if constexpr (!BRES) __syncthreads();
   };
 
-  for (int g = 0; g < total; g += 4) {
+  for (int g = 0; g < total; g += NSET) {
     step(std::integral_constant<int, 0>{}, g);
     if (g + 1 < total) step(std::integral_constant<int, 1>{}, g + 1);
     if (g + 2 < total) step(std::integral_constant<int, 2>{}, g + 2);
     if (g + 3 < total) step(std::integral_constant<int, 3>{}, g + 3);
+    if constexpr (NSET > 4) {
+      if (g + 4 < total) step(std::integral_constant<int, 4 % NSET>{}, g + 4);
+      if (g + 5 < total) step(std::integral_constant<int, 5 % NSET>{}, g + 5);
+      if (g + 6 < total) step(std::integral_constant<int, 6 % NSET>{}, g + 6);
+    }
   }
+  if constexpr (BRES) __syncthreads();   // the strips double as the reduction buffer below
 
 #undef G1_LOAD_B
 #undef G1_STORE_B
@@ -273,7 +292,9 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_kernel(const G1Args a) {
   }
 }
 
-struct G1Geom { int NT, n_tiles, m_tiles, G, rows; size_t lds; };
+namespace {
+
+struct G1Geom { int NT, n_tiles, m_tiles, G, rows, bres; size_t lds; };
 
 static G1Geom g1_geom(const ConvArgs& a) {
   G1Geom g;
@@ -282,13 +303,17 @@ static G1Geom g1_geom(const ConvArgs& a) {
   g.n_tiles = (a.Cout + BN - 1) / BN;
   const long long M = (long long)a.N * a.OH * a.OW;
   g.m_tiles = (int)((M + G1_BM - 1) / G1_BM);
-  int gm = G1_MAXWG / g.n_tiles;
+  // opt-in (OCTSEG_G1_BRES=1): measured SLOWER than the streaming form on U-Net++/resnet101 (bottleneck conv3 forward 1.97 -> 2.66 ms
+  // per step, conv1 data gradients 1.74 -> 2.24): four waves per CU do not cover the HBM latency that eight (two workgroups) do
+  static const bool use_bres = getenv("OCTSEG_G1_BRES") != nullptr;
+  g.bres = (use_bres && g.NT == 4 && a.Cin <= 256 && a.Cin >= 128 && g.n_tiles >= 4) ? 1 : 0;
+  int gm = (g.bres ? G1_MAXWG / 2 : G1_MAXWG) / g.n_tiles;   // BRES: one workgroup per CU
   if (gm < 1) gm = 1;
   if (gm > g.m_tiles) gm = g.m_tiles;
   g.rows = gm;
   g.G = gm * g.n_tiles;
   const bool aff = a.src[0].scale != nullptr;
-  g.lds = (size_t)2 * BN * 128 + (size_t)4 * 32 * (BN * 2 + 16) + (aff ? (size_t)a.Cin * 8 : 0);
+  g.lds = (size_t)(g.bres ? 4 : 2) * BN * 128 + (size_t)4 * 32 * (BN * 2 + 16) + (aff ? (size_t)a.Cin * 8 : 0);
   return g;
 }
 
@@ -311,18 +336,23 @@ bool gemm1x1_eligible(const ConvArgs& a, int dtype) {
 
 int gemm1x1_rows(const ConvArgs& a) { return g1_geom(a).rows; }
 
+template <typename T, int NT, bool AFF, bool BRES>
+static hipError_t g1_launch_k(const G1Args& ga, const G1Geom& g, hipStream_t st) {
+  static bool set = false;
+  if (!set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm1x1_kernel<T, NT, AFF, BRES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    set = true;
+  }
+  hipLaunchKernelGGL((gemm1x1_kernel<T, NT, AFF, BRES>), dim3(g.G), dim3(256), g.lds, st, ga);
+  return hipGetLastError();
+}
 template <typename T, int NT>
 static hipError_t g1_launch(const G1Args& ga, const G1Geom& g, bool aff, hipStream_t st) {
-  if (aff) {
-    static bool set = false;
-    if (!set) { hipError_t e = hipFuncSetAttribute((const void*)gemm1x1_kernel<T, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; set = true; }
-    hipLaunchKernelGGL((gemm1x1_kernel<T, NT, true>), dim3(g.G), dim3(256), g.lds, st, ga);
-  } else {
-    static bool set = false;
-    if (!set) { hipError_t e = hipFuncSetAttribute((const void*)gemm1x1_kernel<T, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; set = true; }
-    hipLaunchKernelGGL((gemm1x1_kernel<T, NT, false>), dim3(g.G), dim3(256), g.lds, st, ga);
+  if constexpr (NT == 4) {
+    if (g.bres) return aff ? g1_launch_k<T, NT, true, true>(ga, g, st) : g1_launch_k<T, NT, false, true>(ga, g, st);
   }
-  return hipGetLastError();
+  return aff ? g1_launch_k<T, NT, true, false>(ga, g, st) : g1_launch_k<T, NT, false, false>(ga, g, st);
 }
 
 hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t st) {

@@ -6,9 +6,9 @@ tag=${1:-r1}
 cd /root/repo; export TMPDIR=/tmp
 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_w -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${tag}_w.log 2>&1
-python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_w/*/*.db | head -1) gpurun_out/${tag}_w_bench_kernel_stats.csv > gpurun_out/prof_${tag}_w.txt
+python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_w/*/*.db | head -1) gpurun_out/${tag}_w_bench_kernel_stats.csv 8 > gpurun_out/prof_${tag}_w.txt
 OCTSEG_NO_SIDE_STREAM=1 OCTSEG_NO_FWD_LANES=1 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_serial -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${tag}_serial.log 2>&1
-python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_serial/*/*.db | head -1) gpurun_out/${tag}_serial_kernel_stats.csv > gpurun_out/prof_${tag}_serial.txt
+python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_serial/*/*.db | head -1) gpurun_out/${tag}_serial_kernel_stats.csv 8 > gpurun_out/prof_${tag}_serial.txt
 python3 tools/collect_traffic.py ${tag} > gpurun_out/${tag}_traffic.log 2>&1
 rm -rf gpurun_out/prof_${tag}_w gpurun_out/prof_${tag}_serial gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
 OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_alone.csv python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

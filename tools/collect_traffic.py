@@ -13,7 +13,7 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(f'{out}/*/*counter_collection.csv')[0]
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
         agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
     res[ctr] = {k: (v[0], v[1]) for k, v in agg.items()}
 rows = {}

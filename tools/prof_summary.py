@@ -15,5 +15,6 @@ if out:
             w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 2), r[4], r[5]])
 print(f'total kernel time {tot / 1e6:.2f} ms over {steps} steps')
 for r in rows[:30]:
-    n = re.sub(r'\(.*', '', r[0])[:78]
+    n = re.sub(r'\(anonymous namespace\)::', '', r[0])
+    n = re.sub(r'\(.*', '', n)[:78]
     print(f'{n:78s} {r[1]:6d} {r[2] / 1e6 / steps:8.2f} ms/step {100 * r[2] / tot:5.1f}%')
