@@ -1,0 +1,411 @@
+// conv3x3p.hip -- persistent 3x3 stride-1 convolution (forward and data gradient) for the 2-byte dtypes on gfx950.
+//
+// Why: conv_mfma_kernel runs ONE output tile per workgroup and one workgroup per CU (141 KiB of LDS).  Its main loop holds
+// ~1.2 PFLOP/s (slope of time over K), but every tile round also pays ~26 us that no MFMA covers: all 256 CUs fill their first
+// window + slabs from HBM at the same moment, and drain their 64 KiB output tile at the same moment (s_memtime stamps, 512 ->
+// 256 @176^2: prologue 23.5 k + epilogue 18.4 k ticks against 210 k of main loop; on the K-thin data gradients the two exceed
+// the main loop).  Here a workgroup is persistent: it walks its tiles with ONE software pipeline over the flattened
+// (tile, K chunk, tap) sequence -- the first window and slabs of the next tile are staged during the last taps of this one,
+// and the epilogue's global stores drain under the next tile's MFMAs.  Tile, wave layout, window pitch, weight image and
+// the lazy-BN staging are those of conv_mfma_kernel's <T, 2, 2, 4, 128> configuration (16x16 pixels x 128 channels, 8 waves,
+// 64-channel K chunks, grouped A-row map); the pipeline is plain HIP (hipcc places every wait):
+//   tap t:  LDS-store the weight slab of step g+1 and the window slice of pass t-1 (both loaded during tap t-1),
+//           issue the loads of the slab of step g+2 and of window pass t (next chunk: possibly the next tile's first),
+//           16 MFMAs per wave from the current window / slab slot, one barrier.
+// The epilogue transposes the tile through the window buffer it has just finished with, half a tile (128 pixels) at a time.
+// Eligible launches (launch_conv routes them here): 9 taps, stride 1, interior tiles only (OH, OW multiples of 16), the
+// 128-channel N tile, K >= 128, >= 2 tiles per workgroup, no NCHW head.  Everything else stays on conv_mfma_kernel.
+// RESULT (round 2): results bit-identical to conv_mfma_kernel's (same accumulation order); speed about EQUAL overall -- the
+// overlap of the next tile's fill buys what the plain-HIP main loop loses to the hand-scheduled one (run9r: LDS-DMA slabs,
+// counted waits).  The structure is the base for the next round (LDS-DMA slab ring + epilogue stores overlapped as well).
+#include "common.h"
+#include "conv_common.h"
+#include "kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace octseg {
+
+namespace {
+constexpr int P3_NT = 2, P3_WN = 2, P3_WM = 4, P3_RB = 128, P3_BN = 128, P3_TH = 16;
+constexpr int P3_NTHREADS = 512, P3_PITCH = P3_RB + 16, P3_SLAB = P3_BN * P3_RB;
+constexpr int P3_RW = 18, P3_NPIX = 18 * 18, P3_PSTEP = P3_NTHREADS / (P3_RB / 16), P3_NPASS = (P3_NPIX + P3_PSTEP - 1) / P3_PSTEP;
+constexpr int P3_ABYTES = P3_NPASS * P3_PSTEP * P3_PITCH;
+constexpr int P3_OPITCH = P3_BN * 2 + 16;
+static_assert(P3_NPASS <= 8, "one window pass per tap");
+// grouped A-row map (conv_mfma.hip RowMap<true>): the 16 lanes of one ds_read_b128 LDS cycle read 16 consecutive pixels of a row
+__device__ __forceinline__ int p3_ty(int rr) { return (0xF00F0FF0u >> rr) & 1; }
+__device__ __forceinline__ int p3_tx(int rr) {
+  const unsigned grp = ((0xF00F0FF0u >> rr) & 1) ? 0xF00F0FF0u : ~0xF00F0FF0u;
+  return __popc(grp & ((1u << rr) - 1u));
+}
+}  // namespace
+
+template <typename T, bool FILL>
+__global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs a, const int n_nt, const int tiles_x, const int tiles_y,
+                                                                   const int nitems) {
+  constexpr int NT = P3_NT, WN = P3_WN, WM = P3_WM, RB = P3_RB, BN = P3_BN, PITCH = P3_PITCH, SLAB = P3_SLAB;
+  constexpr int KC = RB / 2, KSTEPS = RB / 32, VPR = RB / 16, NPASS = P3_NPASS, RW = P3_RW, OPITCH = P3_OPITCH;
+  typedef WindowStager<T, RB, P3_NTHREADS> Stager;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;                       // [2] windows
+  char* ldsB = smem + 2 * P3_ABYTES;       // [2] weight slabs
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int G = gridDim.x;
+  const int wid = blockIdx.x;
+  const int l = (G & 7) == 0 ? (wid & 7) * (G >> 3) + (wid >> 3) : wid;   // XCD x owns a contiguous range of the item order
+  const int nloc = (nitems - l + G - 1) / G;
+  const int nchunks = (a.Cin + KC - 1) / KC;
+  const bool usrc = a.src_uniform != 0;
+
+  // item -> tile: N tile fastest (the N tiles of one M tile are neighbours in the item order: its window comes from HBM once)
+  struct Tile { int n, y0, x0, nt, w_mt; };
+  auto tile_of = [&](int it) -> Tile {
+    Tile t;
+    t.nt = it % n_nt;
+    int m = it / n_nt;
+    t.w_mt = m;
+    t.n = m / (tiles_x * tiles_y);
+    m -= t.n * tiles_x * tiles_y;
+    const int tyi = m / tiles_x;
+    t.y0 = tyi * P3_TH; t.x0 = (m - tyi * tiles_x) * TW;
+    return t;
+  };
+
+  // ---- fragment addressing
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int ty = wm * 4 + mt * 2 + p3_ty(r), tx = p3_tx(r);
+    abase[mt] = (ty * RW + tx) * PITCH + h * 16;
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (wn * NT * 32 + nt * 32 + r) * RB;
+  const int bswz = (((wn * NT * 32 + r) / 2) & (VPR - 1));   // (rows of one 32-channel sub-tile differ by multiples of 32: same swizzle)
+  // tap tables in VGPR lanes (lane i = tap i), fetched with v_readlane
+  int v_toff = 0, v_tapw = 0;
+  if (lane < 9) {
+    v_toff = ((a.tap_dy[lane] - a.min_dy) * RW + (a.tap_dx[lane] - a.min_dx)) * PITCH;
+    v_tapw = a.tap_w[lane];
+  }
+  // window pixels of this thread's six passes (they do not depend on the tile)
+  const int p0w = tid / VPR;
+  int phy[NPASS], phx[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int hp = min(p * P3_PSTEP + p0w, P3_NPIX - 1);   // (the padding rows of the last pass re-stage the last pixel: never read)
+    phy[p] = hp / RW; phx[p] = hp - phy[p] * RW;
+  }
+
+  f32x16_t acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  // ---- weight slab cursor: two steps ahead of the consumer
+  const char* Wp = (const char*)a.W;
+  const long long slab_stride = (long long)n_nt * SLAB;   // between consecutive (tap, chunk) slabs of one N tile
+  int s_it = l, s_chunk = 0, s_tap = 0, s_nt = l % n_nt;
+  uint4 B0, B1;
+  auto load_slab = [&]() __attribute__((always_inline)) {
+    const int tapw = __builtin_amdgcn_readlane(v_tapw, s_tap);
+    const char* p = Wp + ((long long)(tapw * nchunks + s_chunk)) * slab_stride + (long long)s_nt * SLAB + tid * 16;
+    B0 = *(const uint4*)p; B1 = *(const uint4*)(p + 8192);
+    if (++s_tap == 9) {
+      s_tap = 0;
+      if (++s_chunk == nchunks) {
+        s_chunk = 0;
+        if (s_it + G < nitems) { s_it += G; s_nt = s_it % n_nt; }   // past the last item: stay (harmless re-fetch)
+      }
+    }
+  };
+  auto store_slab = [&](int slot) __attribute__((always_inline)) {
+    char* q = ldsB + slot * SLAB + tid * 16;
+    *(uint4*)q = B0; *(uint4*)(q + 8192) = B1;
+  };
+
+  // ---- window producer: one chunk ahead of the consumer
+  Stager nxt;
+  int n_gy0 = 0, n_gx0 = 0;
+  auto setup_next = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
+    nxt.setup(a.src, a.nsrc, a.Cin, chunk, tid, usrc);
+    nxt.bind_image(t.n);
+    n_gy0 = t.y0 + a.min_dy; n_gx0 = t.x0 + a.min_dx;
+  };
+  uint4 sl = make_uint4(0, 0, 0, 0);
+  bool sl_ok = false;
+
+  // ---- prologue: window of (first tile, chunk 0), slab of step 0 in slot 0, slab of step 1 in registers
+  Tile cur = tile_of(l);
+  {
+    setup_next(cur, 0);
+    load_slab();
+    uint4 v[NPASS]; bool ok[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) v[p] = nxt.load_at(phy[p], phx[p], true, n_gy0, n_gx0, 1, a.IH, a.IW, ok[p]);
+    store_slab(0);
+    load_slab();
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) nxt.write_at(ldsA + (p * P3_PSTEP + p0w) * PITCH, v[p], ok[p]);
+  }
+  __syncthreads();
+
+  int it = l, chunk = 0, cb = 0;   // consumer: item, chunk, window buffer of the chunk
+  int sp = 0;                      // slab slot of tap 0 of the chunk (nine taps per chunk: the parity flips every chunk)
+  Tile nt_tile = cur;              // tile of the chunk being staged
+
+  // ---- epilogue of the finished tile `cur` through window buffer `buf` (every wave is past its last read of it)
+  auto epilogue = [&](char* buf) __attribute__((always_inline)) {
+    char* otile = buf;                                     // [128 pixels of a half tile][OPITCH]
+    float* red = (float*)(buf + 128 * OPITCH);             // [WM][BN][2]
+    const int co0 = cur.nt * BN;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = co0 + wn * NT * 32 + nt * 32 + r;
+      bias[nt] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+    const float ofloor = a.relu_out ? 0.f : -3.0e38f;
+    // this thread's share of the store sweep: channel vector cvv, pixel (rloc, tx) of every wave-row group
+    const int cvv = tid & 15, tx = (tid >> 4) & 15, rloc = tid >> 8;
+    const int cov = co0 + cvv * 8;
+    char* dptr = (char*)a.dst[0].ptr; int dC = a.dst[0].C, dc0 = a.dst[0].c0, dH = a.dst[0].H, dW = a.dst[0].W, dacc = a.dst[0].accum;
+    int dpool = a.dst[0].pool;
+#pragma unroll
+    for (int i = 1; i < MAX_SRC; ++i)
+      if (i < a.ndst && cov >= a.dst[i].c0) {
+        dptr = (char*)a.dst[i].ptr; dC = a.dst[i].C; dc0 = a.dst[i].c0; dH = a.dst[i].H; dW = a.dst[i].W; dacc = a.dst[i].accum;
+        dpool = a.dst[i].pool;
+      }
+    if (a.out_mode == OUT_ACCUM) dacc = 1;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // transposed half tile into LDS
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float val = fmaxf(acc[mt][nt][i] + bias[nt], ofloor);
+          s1[nt] += val; s2[nt] += val * val;
+          acc[mt][nt][i] = 0.f;
+          const int rl = h ^ ((0x6 >> (i >> 2)) & 1);     // grouped row map: row of the strip, column 4 * (i >> 2) + (i & 3)
+          const int q = wm * 32 + rl * 16 + 4 * (i >> 2) + (i & 3);
+          *(unsigned short*)(otile + q * OPITCH + (wn * NT * 32 + nt * 32 + r) * 2) = Tr<T>::bits16(val);
+        }
+      __syncthreads();
+      if (cov < a.Cout) {
+        if (dpool) {
+          // gradient of a nearest-x2 upsample: each 2x2 quad summed in f32, one rounding, at half resolution
+          if (rloc == 0 && (tx & 1) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int ty = k * 4 + mt * 2;
+              const char* l0 = otile + (k * 32 + tx) * OPITCH + cvv * 16;
+              const uint4 qv[4] = {*(const uint4*)l0, *(const uint4*)(l0 + OPITCH), *(const uint4*)(l0 + 16 * OPITCH),
+                                   *(const uint4*)(l0 + 17 * OPITCH)};
+              uint4* gq = (uint4*)(dptr + ((((size_t)cur.n * dH + ((cur.y0 + ty) >> 1)) * dW + ((cur.x0 + tx) >> 1)) * dC + (cov - dc0)) * 2);
+              uint4 old = make_uint4(0, 0, 0, 0);
+              if (dacc) old = *gq;
+              const unsigned o[4] = {old.x, old.y, old.z, old.w};
+              const unsigned* qq[4] = {&qv[0].x, &qv[1].x, &qv[2].x, &qv[3].x};
+              unsigned r4[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float lo = dacc ? Tr<T>::lo(o[i]) : 0.f, hi = dacc ? Tr<T>::hi(o[i]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo += Tr<T>::lo(qq[j][i]); hi += Tr<T>::hi(qq[j][i]); }
+                r4[i] = Tr<T>::pk(lo, hi);
+              }
+              *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+            }
+          }
+        } else {
+          const size_t rowb = (size_t)dW * dC * 2;
+          char* gp = dptr + ((((size_t)cur.n * dH + cur.y0 + mt * 2 + rloc) * dW + cur.x0 + tx) * dC + (cov - dc0)) * 2;
+          const char* lp = otile + (rloc * 16 + tx) * OPITCH + cvv * 16;
+          if (dacc) {
+            uint4 old[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) old[k] = *(const uint4*)(gp + (size_t)k * 4 * rowb);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint4 val = *(const uint4*)(lp + k * 32 * OPITCH);
+              float x0[8], x1[8];
+              Tr<T>::unpack8(val, x0); Tr<T>::unpack8(old[k], x1);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x0[e] += x1[e];
+              *(uint4*)(gp + (size_t)k * 4 * rowb) = Tr<T>::pack8(x0);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint4*)(gp + (size_t)k * 4 * rowb) = *(const uint4*)(lp + k * 32 * OPITCH);
+          }
+        }
+      }
+      __syncthreads();   // the half tile is consumed before the next half (or the next chunk's window slices) overwrites it
+    }
+    if (a.stat_slab != nullptr) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+        if (h == 0) {
+          const int cl = wn * NT * 32 + nt * 32 + r;
+          red[(wm * BN + cl) * 2 + 0] = s1[nt];
+          red[(wm * BN + cl) * 2 + 1] = s2[nt];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && co0 + tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+        float* slab = a.stat_slab + ((size_t)(a.slab_row0 + cur.w_mt) * a.Cout + co0 + tid) * 2;
+        slab[0] = t1; slab[1] = t2;
+      }
+      __syncthreads();
+    }
+  };
+
+  // ---- one tap
+  auto tap = [&](auto tc) __attribute__((always_inline)) {
+    constexpr int TT = decltype(tc)::value;
+    char* awin = ldsA + cb * P3_ABYTES;
+    char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
+    if constexpr (TT == 0) {   // which chunk is staged during this one: the next chunk of the tile, or the first of the next tile
+      if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
+      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+    }
+    // 16 MFMAs per wave; behind the MFMAs of k-step 0: what the previous tap loaded goes to LDS (the slab of the next step,
+    // window pass TT - 1 of the chunk being staged); behind k-step 1: this tap's loads (the slab of step g + 2, window pass TT).
+    // The MFMAs just issued execute while the wave runs the filler -- stores at the head of the tap would sit in the LDS queue in
+    // front of the tap's own fragment reads.
+    if constexpr (!FILL) {   // A/B variant: stores and loads at the head of the tap
+      store_slab(((TT + 1) & 1) ^ sp);
+      if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
+      load_slab();
+      if constexpr (TT < NPASS) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
+    }
+    const int toff = __builtin_amdgcn_readlane(v_toff, TT);
+    const char* bsl = ldsB + ((TT & 1) ^ sp) * SLAB;
+    uint4 af[3][2], bf[3][NT];
+    auto frag_load = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz) * 16));
+    };
+    frag_load(0, 0);
+    frag_load(1, 1);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (FILL && ks == 0) {
+        store_slab(((TT + 1) & 1) ^ sp);
+        if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
+      }
+      if (FILL && ks == 1) {
+        load_slab();
+        if constexpr (TT < NPASS) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+
+  const int total_chunks = nloc * nchunks;
+  for (int cc = 0; cc < total_chunks; ++cc) {
+    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    sp ^= 1;
+    if (chunk + 1 < nchunks) { ++chunk; }
+    else {
+      epilogue(ldsA + cb * P3_ABYTES);
+      chunk = 0; it += G; cur = nt_tile;
+    }
+    cb ^= 1;
+  }
+}
+
+namespace {
+struct P3Geom { int tiles_x, tiles_y, n_mt, n_nt, nitems, G; size_t lds; };
+static P3Geom p3_geom(const ConvArgs& a) {
+  P3Geom g;
+  g.tiles_x = a.OW / TW; g.tiles_y = a.OH / P3_TH;
+  g.n_mt = a.N * g.tiles_x * g.tiles_y;
+  g.n_nt = (a.Cout + P3_BN - 1) / P3_BN;
+  g.nitems = g.n_mt * g.n_nt;
+  g.G = g.nitems < 256 ? g.nitems : 256;   // one workgroup per CU (gfx950 / MI355X only build)
+  g.lds = (size_t)2 * P3_ABYTES + 2 * P3_SLAB;
+  return g;
+}
+}  // namespace
+
+bool conv3x3p_eligible(const ConvArgs& a, int dtype) {
+  static const bool on = getenv("OCTSEG_NO_CONV3X3P") == nullptr;   // A/B switch
+  if (!on || dtype == DT_F32) return false;
+  if (a.ntaps != 9 || a.istride != 1 || a.ostride != 1 || a.ooy != 0 || a.oox != 0 || a.out_mode == OUT_HEAD_NCHW) return false;
+  if (a.span_x != 3 || a.span_y != 3 || a.OH % P3_TH != 0 || a.OW % TW != 0 || a.IH != a.OH || a.IW != a.OW) return false;
+  // the 128-channel N tile with 64-channel K chunks; K >= 128: measured on one box against conv_mfma_kernel (U-Net++/resnet101 16 x 704^2,
+  // profiles/r2_conv3x3p_ab.txt) the wide data gradients gain (768 <- 256 @176^2 2000 -> 1813 us, 1024 <- 256 2586 -> 2525) and the
+  // forwards 0..3 %, but the single-chunk (K = 64) data gradients lose 5..7 % to run9s, whose window never restages
+  if (a.Cout <= 64 || a.Cin < 128 || a.Cout % 8 != 0) return false;
+  for (int i = 0; i < a.ndst; ++i) {
+    const DstDesc& d = a.dst[i];
+    if (d.pool ? (d.H * 2 != a.OH || d.W * 2 != a.OW) : (d.H != a.OH || d.W != a.OW)) return false;
+    if (d.c0 % 8 != 0) return false;
+  }
+  const ConvPackInfo pk = conv_pack_info(a, dtype);
+  if (pk.BN != P3_BN || pk.RB != P3_RB) return false;                         // (the wide-N configuration keeps its layers)
+  const long long items = (long long)a.N * (a.OH / P3_TH) * (a.OW / TW) * ((a.Cout + P3_BN - 1) / P3_BN);
+  return items >= 512;                                                        // persistence needs at least two tiles per workgroup
+}
+
+int conv3x3p_rows(const ConvArgs& a) { return p3_geom(a).n_mt; }
+
+template <typename T, bool FILL>
+static hipError_t p3_launch_k(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
+  static bool set = false;
+  if (!set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<T, FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    set = true;
+  }
+  hipLaunchKernelGGL((conv3x3p_kernel<T, FILL>), dim3(g.G), dim3(P3_NTHREADS), g.lds, st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t p3_launch(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
+  static const bool head = getenv("OCTSEG_P3_HEAD") != nullptr;   // A/B switch: loads / stores at the head of the tap
+  return head ? p3_launch_k<T, false>(a, g, st) : p3_launch_k<T, true>(a, g, st);
+}
+
+hipError_t launch_conv3x3p(int dtype, const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  a.src_uniform = 1;
+  for (int i = 1; i < a.nsrc; ++i)
+    if (a.src[i].c0 % 64 != 0) a.src_uniform = 0;
+  const P3Geom g = p3_geom(a);
+  if (dtype == DT_F16) return p3_launch<f16_t>(a, g, st);
+  return p3_launch<bf16_t>(a, g, st);
+}
+
+}  // namespace octseg

@@ -440,6 +440,10 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   constexpr int MAXP = 4;                                     // window passes prefetched per tap
   typedef WindowStager<T, RB, NTHREADS> Stager;
 
+#ifdef OCTSEG_STAMP
+  unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+  STAMP(k0);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
@@ -602,6 +606,9 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef OCTSEG_STAMP
+  STAMP(k1);
+#endif
 
   // ---------------- main loop ----------------
   // PPT = window passes of the NEXT chunk prefetched per tap (1 for multi-tap convs, 4 for 1x1);
@@ -949,11 +956,16 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   }
 
 #ifdef OCTSEG_STAMP
-  if (a.stamp != nullptr && lane == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
+  STAMP(k2);
 #endif
-
   conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED, MT>(a, smem, acc, tp);
+#ifdef OCTSEG_STAMP
+  STAMP(k3);
+  if (a.stamp != nullptr && lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(a.stamp + i, tsum[i]);
+    atomicAdd(a.stamp + 8, k1 - k0); atomicAdd(a.stamp + 9, k2 - k1); atomicAdd(a.stamp + 10, k3 - k2); atomicAdd(a.stamp + 11, 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1192,6 +1204,7 @@ static bool flatten_1x1(ConvArgs& a) {
 
 int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
   if (gemm1x1_eligible(a0, dtype)) return gemm1x1_rows(a0);
+  if (conv3x3p_eligible(a0, dtype)) return conv3x3p_rows(a0);
   ConvArgs a = a0;
   flatten_1x1(a);
   return conv_num_mtiles(a, dtype);
@@ -1200,6 +1213,7 @@ int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
 hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
   if (a0.ntaps <= 0) return hipSuccess;
   if (gemm1x1_eligible(a0, dtype)) return launch_gemm1x1(dtype, a0, st);
+  if (conv3x3p_eligible(a0, dtype)) return launch_conv3x3p(dtype, a0, st);
   ConvArgs a = a0;
   flatten_1x1(a);
   {

@@ -27,6 +27,12 @@ hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t st);
 // workgroup's -- weight gradients without split-K, Dice sums and bias gradients by one workgroup per output.  Slower; bit-stable.
 bool deterministic_mode();
 
+// conv3x3p.hip: persistent 3x3 stride-1 conv / data gradient (2-byte dtypes, interior tiles, 128-channel N tile): one software pipeline
+// over the flattened (tile, K chunk, tap) sequence of a workgroup; same weight image and BN-stat slab rows as conv_mfma_kernel's 16x16 tile
+bool conv3x3p_eligible(const ConvArgs& a, int dtype);
+int conv3x3p_rows(const ConvArgs& a);
+hipError_t launch_conv3x3p(int dtype, const ConvArgs& a, hipStream_t st);
+
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 

@@ -31,6 +31,9 @@ CASES = [
     (2, 24, 24, 64, 16, 1, 1, 0, False),     # LinkNet decoder tail: one 32-wide N tile, one K step
     (8, 96, 96, 64, 64, 1, 1, 0, False),     # 576 M tiles > 512 workgroups: some walk two tiles (pipeline across the tile boundary)
     (5, 96, 96, 128, 256, 1, 1, 0, False),   # 360 M tiles x 2 N tiles on 256 workgroup rows, two K steps, ragged walk (104 rows do two tiles)
+    # persistent 3x3 kernel (conv3x3p.hip, bf16): 512 tiles x 2 N tiles over 256 workgroups = four tiles each, three K chunks with a
+    # partial last one (136 = 64 + 64 + 8), a half-empty second N tile; forward and data gradient both walk tiles
+    (8, 128, 128, 160, 136, 3, 1, 1, False),
 ]
 
 

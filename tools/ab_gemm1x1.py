@@ -16,7 +16,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 import torch
 cfg = sys.argv[1:6] if len(sys.argv) > 5 else ['unetplusplus', 'resnet101', '1', '16', '704']
 res = {}
-for tag, env in (('new', {}), ('old', {'OCTSEG_NO_GEMM1X1': '1'})):
+SW = os.environ.get('AB_SWITCH', 'OCTSEG_NO_GEMM1X1')
+for tag, env in (('new', {}), ('old', {SW: '1'})):
     e = dict(os.environ); e.update(env)
     subprocess.run([sys.executable, __file__, 'child'] + cfg + [f'/tmp/ab_{tag}.pt'], check=True, env=e)
     res[tag] = torch.load(f'/tmp/ab_{tag}.pt', weights_only=False)

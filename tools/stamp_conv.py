@@ -5,8 +5,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, 'oct_segmentation_amd', 'csrc')
 tmp = tempfile.mkdtemp()
 so = os.path.join(tmp, 'liboctseg_stamp.so')
-srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
-subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-DOCTSEG_STAMP'] + os.environ.get('OCTSEG_EXTRA_DEFS', '').split() + ['-o', so] + srcs, check=True)
+srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'gemm1x1.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
+prebuilt = os.path.join(root, 'oct_segmentation_amd', 'liboctseg_stamp.so')   # built in the build container, travels with the snapshot
+if os.path.exists(prebuilt):
+    so = prebuilt
+else:
+  subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-DOCTSEG_STAMP'] + os.environ.get('OCTSEG_EXTRA_DEFS', '').split() + ['-o', so] + srcs, check=True)
 sys.path.insert(0, root)
 import torch
 from oct_segmentation_amd import _lib as L
