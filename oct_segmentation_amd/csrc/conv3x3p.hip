@@ -114,11 +114,12 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   const char* Wp = (const char*)a.W;
   const long long slab_stride = (long long)n_nt * SLAB;   // between consecutive (tap, chunk) slabs of one N tile
   int s_it = l, s_chunk = 0, s_tap = 0, s_nt = l % n_nt;
-  uint4 B0, B1;
-  auto load_slab = [&]() __attribute__((always_inline)) {
+  uint4 B0, B1;                                           // FILL: slab register set of the even steps ...
+  uint4 C0 = make_uint4(0, 0, 0, 0), C1 = C0;             // ... and of the odd ones (a slab stays in registers for two taps)
+  auto load_slab_into = [&](uint4& b0, uint4& b1) __attribute__((always_inline)) {
     const int tapw = __builtin_amdgcn_readlane(v_tapw, s_tap);
     const char* p = Wp + ((long long)(tapw * nchunks + s_chunk)) * slab_stride + (long long)s_nt * SLAB + tid * 16;
-    B0 = *(const uint4*)p; B1 = *(const uint4*)(p + 8192);
+    b0 = *(const uint4*)p; b1 = *(const uint4*)(p + 8192);
     if (++s_tap == 9) {
       s_tap = 0;
       if (++s_chunk == nchunks) {
@@ -127,10 +128,12 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       }
     }
   };
-  auto store_slab = [&](int slot) __attribute__((always_inline)) {
+  auto load_slab = [&]() __attribute__((always_inline)) { load_slab_into(B0, B1); };
+  auto store_slab_from = [&](int slot, const uint4& b0, const uint4& b1) __attribute__((always_inline)) {
     char* q = ldsB + slot * SLAB + tid * 16;
-    *(uint4*)q = B0; *(uint4*)(q + 8192) = B1;
+    *(uint4*)q = b0; *(uint4*)(q + 8192) = b1;
   };
+  auto store_slab = [&](int slot) __attribute__((always_inline)) { store_slab_from(slot, B0, B1); };
 
   // ---- window producer: one chunk ahead of the consumer
   Stager nxt;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     nxt.bind_image(t.n);
     n_gy0 = t.y0 + a.min_dy; n_gx0 = t.x0 + a.min_dx;
   };
-  uint4 sl = make_uint4(0, 0, 0, 0);
-  bool sl_ok = false;
+  uint4 sl = make_uint4(0, 0, 0, 0), sl2 = sl;   // window passes in flight (FILL: even / odd taps, stored two taps after their load)
+  bool sl_ok = false, sl2_ok = false;
 
   // ---- prologue: window of (first tile, chunk 0), slab of step 0 in slot 0, slab of step 1 in registers
   Tile cur = tile_of(l);
@@ -152,14 +155,14 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) v[p] = nxt.load_at(phy[p], phx[p], true, n_gy0, n_gx0, 1, a.IH, a.IW, ok[p]);
     store_slab(0);
-    load_slab();
+    load_slab();                              // slab of step 1 (FILL: in the even set, stored during step 0)
+    if constexpr (FILL) load_slab_into(C0, C1);   // slab of step 2 (odd set, stored during step 1)
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) nxt.write_at(ldsA + (p * P3_PSTEP + p0w) * PITCH, v[p], ok[p]);
   }
   __syncthreads();
 
   int it = l, chunk = 0, cb = 0;   // consumer: item, chunk, window buffer of the chunk
-  int sp = 0;                      // slab slot of tap 0 of the chunk (nine taps per chunk: the parity flips every chunk)
   Tile nt_tile = cur;              // tile of the chunk being staged
 
   // ---- epilogue of the finished tile `cur` through window buffer `buf` (every wave is past its last read of it)
@@ -279,8 +282,10 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   };
 
   // ---- one tap
-  auto tap = [&](auto tc) __attribute__((always_inline)) {
+  auto tap = [&](auto tc, auto spc) __attribute__((always_inline)) {
     constexpr int TT = decltype(tc)::value;
+    constexpr int SP = decltype(spc)::value;   // parity of the global step of tap 0 of this chunk (nine taps per chunk: it alternates)
+    constexpr int P = (TT + SP) & 1;           // parity of this step = slab slot it reads
     char* awin = ldsA + cb * P3_ABYTES;
     char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
     if constexpr (TT == 0) {   // which chunk is staged during this one: the next chunk of the tile, or the first of the next tile
@@ -292,13 +297,13 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     // The MFMAs just issued execute while the wave runs the filler -- stores at the head of the tap would sit in the LDS queue in
     // front of the tap's own fragment reads.
     if constexpr (!FILL) {   // A/B variant: stores and loads at the head of the tap
-      store_slab(((TT + 1) & 1) ^ sp);
+      store_slab(P ^ 1);
       if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
       load_slab();
       if constexpr (TT < NPASS) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
     }
     const int toff = __builtin_amdgcn_readlane(v_toff, TT);
-    const char* bsl = ldsB + ((TT & 1) ^ sp) * SLAB;
+    const char* bsl = ldsB + P * SLAB;
     uint4 af[3][2], bf[3][NT];
     auto frag_load = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -317,31 +322,43 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
+      // FILL: what was loaded TWO taps ago goes to LDS behind k-step 0 (the slab of the next step from this step's register set, window
+      // pass TT - 2), this tap's loads are issued behind k-step 1 (the slab of step g + 3 into the same set, window pass TT): every
+      // load has 1.75 taps (~2 us) to land before its wait
       if (FILL && ks == 0) {
-        store_slab(((TT + 1) & 1) ^ sp);
-        if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
+        if constexpr (P == 0) store_slab_from(1, B0, B1); else store_slab_from(0, C0, C1);
+        if constexpr (TT >= 2 && TT <= NPASS + 1) {
+          if constexpr ((TT & 1) == 0) nxt.write_at(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
+          else nxt.write_at(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH, sl2, sl2_ok);
+        }
       }
       if (FILL && ks == 1) {
-        load_slab();
-        if constexpr (TT < NPASS) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
+        if constexpr (P == 0) load_slab_into(B0, B1); else load_slab_into(C0, C1);
+        if constexpr (TT < NPASS) {
+          if constexpr ((TT & 1) == 0) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
+          else sl2 = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl2_ok);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
 
-  const int total_chunks = nloc * nchunks;
-  for (int cc = 0; cc < total_chunks; ++cc) {
-    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
-    sp ^= 1;
+  auto chunk_body = [&](auto spc) __attribute__((always_inline)) {
+    tap(std::integral_constant<int, 0>{}, spc); tap(std::integral_constant<int, 1>{}, spc); tap(std::integral_constant<int, 2>{}, spc);
+    tap(std::integral_constant<int, 3>{}, spc); tap(std::integral_constant<int, 4>{}, spc); tap(std::integral_constant<int, 5>{}, spc);
+    tap(std::integral_constant<int, 6>{}, spc); tap(std::integral_constant<int, 7>{}, spc); tap(std::integral_constant<int, 8>{}, spc);
     if (chunk + 1 < nchunks) { ++chunk; }
     else {
       epilogue(ldsA + cb * P3_ABYTES);
       chunk = 0; it += G; cur = nt_tile;
     }
     cb ^= 1;
+  };
+  const int total_chunks = nloc * nchunks;
+  for (int cc = 0; cc < total_chunks; cc += 2) {
+    chunk_body(std::integral_constant<int, 0>{});
+    if (cc + 1 < total_chunks) chunk_body(std::integral_constant<int, 1>{});
   }
 }
 
@@ -395,6 +412,7 @@ static hipError_t p3_launch_k(const ConvArgs& a, const P3Geom& g, hipStream_t st
 template <typename T>
 static hipError_t p3_launch(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
   static const bool head = getenv("OCTSEG_P3_HEAD") != nullptr;   // A/B switch: loads / stores at the head of the tap
+  if (std::is_same<T, f16_t>::value) return p3_launch_k<T, false>(a, g, st);   // (the deep variant's f16 instantiation spills 5 registers)
   return head ? p3_launch_k<T, false>(a, g, st) : p3_launch_k<T, true>(a, g, st);
 }
 
