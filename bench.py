@@ -42,6 +42,67 @@ WORKLOADS = {
 }
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU, read from its hwmon files every 20 ms by a thread while the timed steps run (the conv
+    loops sit on the package power limit on real operands -- profiles/r2_power_probe.txt -- so the clock they are given is part of
+    reading `roofline.frac`).  Best effort: every field is None where the box does not expose the files."""
+
+    def __init__(self, dev):
+        import glob
+        self.power = self.freq = self.cap = None
+        self.samples = []
+        dirs = []
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+            dirs = glob.glob(f'/sys/bus/pci/devices/{bdf}/hwmon/hwmon*')
+        except Exception:
+            pass
+        if not dirs:
+            dirs = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))[:1]
+        for d in dirs:
+            for name in ('power1_average', 'power1_input'):
+                if self.power is None and os.path.exists(os.path.join(d, name)):
+                    self.power = os.path.join(d, name)
+            if os.path.exists(os.path.join(d, 'freq1_input')):
+                self.freq = os.path.join(d, 'freq1_input')
+            if os.path.exists(os.path.join(d, 'power1_cap')):
+                self.cap = os.path.join(d, 'power1_cap')
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.samples.append((self._read(self.power) if self.power else None, self._read(self.freq) if self.freq else None))
+            time.sleep(0.02)
+
+    def start(self):
+        import threading
+        if self.power or self.freq:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        pw = [p for p, _ in self.samples if p is not None]
+        fq = [f for _, f in self.samples if f is not None]
+        cap = self._read(self.cap) if self.cap else None
+        return {'socket_w': round(sum(pw) / len(pw) / 1e6, 1) if pw else None,
+                'sclk_mhz': round(sum(fq) / len(fq) / 1e6, 1) if fq else None,
+                'cap_w': round(cap / 1e6, 1) if cap else None, 'samples': len(self.samples),
+                'note': 'hwmon power1_average / freq1_input of this GPU, sampled every 20 ms over the timed steps (rank 0)'}
+
+
 def host_cores():
     """CPU threads this job may really use: the affinity mask, cut down to the cgroup CPU quota when there is one.  A one-GPU job
     on the GPU boxes sees every core of the host in its affinity mask but is scheduled on a 16-core share; running oneDNN with
@@ -302,11 +363,15 @@ def main():
     barrier()
     note(f'timing {args.steps} steps')
     L.check(L.lib().octseg_profile_start())
+    sampler = PowerSampler(dev) if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler is not None else None
     prof = (C.c_double * 12)()
     L.check(L.lib().octseg_profile_stop(prof))
     loss_val = float(loss.item())
@@ -356,6 +421,7 @@ def main():
             'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+Dice+bwd+allreduce+{args.optimizer}',
                        'global_batch': global_batch, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
             'loss': round(loss_val, 6),
+            'power': power,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,

@@ -42,7 +42,14 @@ __device__ __forceinline__ int p3_tx(int rr) {
 }
 }  // namespace
 
-template <typename T, bool FILL>
+// ILV = false: weight slab and window slice of the next step go to LDS at the head of the tap and the loads of the step after are issued
+// right behind them (two slab slots, fragments fetched at the head of the tap).  ILV = true (bf16 default): three slab slots, loads two
+// taps ahead of their LDS stores (two register sets), the first two fragment sets of the NEXT tap fetched behind this tap's last MFMAs and
+// kept in flight across the barrier, and the tap cut into sixteen fenced slots of {MFMA, fragment read, a piece of the staging code}
+// (branch-free staging, slab cursor resolved at compile time).  Both are bit-identical; on one box they run within 2 % of each other,
+// because on real operands the loop sits on the 1400 W package limit and its time follows the energy of a tile, not the order of its
+// instructions (profiles/r2_conv3x3p_probe.txt, profiles/r2_power_probe.txt).
+template <typename T, bool ILV>
 __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs a, const int n_nt, const int tiles_x, const int tiles_y,
                                                                    const int nitems) {
   constexpr int NT = P3_NT, WN = P3_WN, WM = P3_WM, RB = P3_RB, BN = P3_BN, PITCH = P3_PITCH, SLAB = P3_SLAB;
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   typedef WindowStager<T, RB, P3_NTHREADS> Stager;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;                       // [2] windows
-  char* ldsB = smem + 2 * P3_ABYTES;       // [2] weight slabs
+  char* ldsB = smem + 2 * P3_ABYTES;       // [2] weight slabs ([3] with ILV: slot = step % 3 = tap % 3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -95,12 +102,15 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   }
   // window pixels of this thread's six passes (they do not depend on the tile)
   const int p0w = tid / VPR;
-  int phy[NPASS], phx[NPASS];
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
+  // (window pixel of pass p: computed where it is used -- twelve registers of pass tables cost more than four VALU per tap)
+  auto pass_y = [&](int p) __attribute__((always_inline)) {
     const int hp = min(p * P3_PSTEP + p0w, P3_NPIX - 1);   // (the padding rows of the last pass re-stage the last pixel: never read)
-    phy[p] = hp / RW; phx[p] = hp - phy[p] * RW;
-  }
+    return (hp * 3641) >> 16;                               // hp / 18 for hp < 324
+  };
+  auto pass_x = [&](int p) __attribute__((always_inline)) {
+    const int hp = min(p * P3_PSTEP + p0w, P3_NPIX - 1);
+    return hp - ((hp * 3641) >> 16) * RW;
+  };
 
   f32x16_t acc[2][NT];
 #pragma unroll
@@ -114,8 +124,8 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   const char* Wp = (const char*)a.W;
   const long long slab_stride = (long long)n_nt * SLAB;   // between consecutive (tap, chunk) slabs of one N tile
   int s_it = l, s_chunk = 0, s_tap = 0, s_nt = l % n_nt;
-  uint4 B0, B1;                                           // FILL: slab register set of the even steps ...
-  uint4 C0 = make_uint4(0, 0, 0, 0), C1 = C0;             // ... and of the odd ones (a slab stays in registers for two taps)
+  uint4 B0, B1;                                           // slab registers (ILV: the set of the even steps ...
+  uint4 C0 = make_uint4(0, 0, 0, 0), C1 = C0;             // ... and of the odd ones: a slab stays in registers for two taps)
   auto load_slab_into = [&](uint4& b0, uint4& b1) __attribute__((always_inline)) {
     const int tapw = __builtin_amdgcn_readlane(v_tapw, s_tap);
     const char* p = Wp + ((long long)(tapw * nchunks + s_chunk)) * slab_stride + (long long)s_nt * SLAB + tid * 16;
@@ -129,6 +139,22 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     }
   };
   auto load_slab = [&]() __attribute__((always_inline)) { load_slab_into(B0, B1); };
+  // ILV: the tap of the slab is known at compile time (consumer tap + 4), the wrap is branch-free
+  const int g_mod = G % n_nt;
+  auto load_slab_ct = [&](auto tic, uint4& b0, uint4& b1) __attribute__((always_inline)) {
+    constexpr int TI = decltype(tic)::value;
+    const int tapw = __builtin_amdgcn_readlane(v_tapw, TI);
+    const char* p = Wp + ((long long)(tapw * nchunks + s_chunk)) * slab_stride + (long long)s_nt * SLAB + tid * 16;
+    b0 = *(const uint4*)p; b1 = *(const uint4*)(p + 8192);
+    if constexpr (TI == 8) {
+      const bool wrap = s_chunk + 1 == nchunks;
+      s_chunk = wrap ? 0 : s_chunk + 1;
+      const bool more = wrap && s_it + G < nitems;
+      s_it = more ? s_it + G : s_it;
+      const int nn = s_nt + g_mod;
+      s_nt = more ? (nn >= n_nt ? nn - n_nt : nn) : s_nt;
+    }
+  };
   auto store_slab_from = [&](int slot, const uint4& b0, const uint4& b1) __attribute__((always_inline)) {
     char* q = ldsB + slot * SLAB + tid * 16;
     *(uint4*)q = b0; *(uint4*)(q + 8192) = b1;
@@ -143,7 +169,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     nxt.bind_image(t.n);
     n_gy0 = t.y0 + a.min_dy; n_gx0 = t.x0 + a.min_dx;
   };
-  uint4 sl = make_uint4(0, 0, 0, 0), sl2 = sl;   // window passes in flight (FILL: even / odd taps, stored two taps after their load)
+  uint4 sl = make_uint4(0, 0, 0, 0), sl2 = sl;   // window passes in flight (ILV: even / odd taps, stored two taps after their load)
   bool sl_ok = false, sl2_ok = false;
 
   // ---- prologue: window of (first tile, chunk 0), slab of step 0 in slot 0, slab of step 1 in registers
@@ -153,14 +179,32 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     load_slab();
     uint4 v[NPASS]; bool ok[NPASS];
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) v[p] = nxt.load_at(phy[p], phx[p], true, n_gy0, n_gx0, 1, a.IH, a.IW, ok[p]);
+    for (int p = 0; p < NPASS; ++p) v[p] = nxt.load_at(pass_y(p), pass_x(p), true, n_gy0, n_gx0, 1, a.IH, a.IW, ok[p]);
     store_slab(0);
-    load_slab();                              // slab of step 1 (FILL: in the even set, stored during step 0)
-    if constexpr (FILL) load_slab_into(C0, C1);   // slab of step 2 (odd set, stored during step 1)
+    load_slab();                              // slab of step 1
+    if constexpr (ILV) {                      // step 1 published too; steps 2 and 3 in the even / odd register set (stored during steps 0 / 1)
+      store_slab(1);
+      load_slab();
+      load_slab_into(C0, C1);
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) nxt.write_at(ldsA + (p * P3_PSTEP + p0w) * PITCH, v[p], ok[p]);
   }
   __syncthreads();
+
+  // fragment sets (three in rotation; with ILV they live across taps: k-step ks of tap TT sits in set (TT + ks) % 3)
+  uint4 af[3][2], bf[3][NT];
+  auto frag_load = [&](int buf, const char* win, int toff, const char* bsl, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(win + abase[mt] + toff + ks * 32);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz) * 16));
+  };
+  if constexpr (ILV) {
+    const int t0 = __builtin_amdgcn_readlane(v_toff, 0);
+    frag_load(0, ldsA, t0, ldsB, 0);
+    frag_load(1, ldsA, t0, ldsB, 1);
+  }
 
   int it = l, chunk = 0, cb = 0;   // consumer: item, chunk, window buffer of the chunk
   Tile nt_tile = cur;              // tile of the chunk being staged
@@ -281,7 +325,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     }
   };
 
-  // ---- one tap
+  // ---- one tap (ILV = false)
   auto tap = [&](auto tc, auto spc) __attribute__((always_inline)) {
     constexpr int TT = decltype(tc)::value;
     constexpr int SP = decltype(spc)::value;   // parity of the global step of tap 0 of this chunk (nine taps per chunk: it alternates)
@@ -292,62 +336,104 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
       else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
     }
-    // 16 MFMAs per wave; behind the MFMAs of k-step 0: what the previous tap loaded goes to LDS (the slab of the next step,
-    // window pass TT - 1 of the chunk being staged); behind k-step 1: this tap's loads (the slab of step g + 2, window pass TT).
-    // The MFMAs just issued execute while the wave runs the filler -- stores at the head of the tap would sit in the LDS queue in
-    // front of the tap's own fragment reads.
-    if constexpr (!FILL) {   // A/B variant: stores and loads at the head of the tap
-      store_slab(P ^ 1);
-      if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
-      load_slab();
-      if constexpr (TT < NPASS) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
-    }
+    // what the previous tap loaded goes to LDS (the slab of the next step, window pass TT - 1 of the chunk being staged), then this
+    // tap's loads are issued (the slab of step g + 2, window pass TT): a whole tap of MFMAs to land behind
+    store_slab(P ^ 1);
+    if constexpr (TT >= 1 && TT <= NPASS) nxt.write_at(anext + ((TT - 1) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
+    load_slab();
+    if constexpr (TT < NPASS) sl = nxt.load_at(pass_y(TT), pass_x(TT), true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
     const int toff = __builtin_amdgcn_readlane(v_toff, TT);
     const char* bsl = ldsB + P * SLAB;
-    uint4 af[3][2], bf[3][NT];
-    auto frag_load = [&](int buf, int ks) __attribute__((always_inline)) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[buf][mt] = *(const uint4*)(awin + abase[mt] + toff + ks * 32);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz) * 16));
-    };
-    frag_load(0, 0);
-    frag_load(1, 1);
+    frag_load(0, awin, toff, bsl, 0);
+    frag_load(1, awin, toff, bsl, 1);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, ks + 2);
+      if (ks + 2 < KSTEPS) frag_load((ks + 2) % 3, awin, toff, bsl, ks + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) Tr<T>::mma(af[ks % 3][mt], bf[ks % 3][nt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
-      // FILL: what was loaded TWO taps ago goes to LDS behind k-step 0 (the slab of the next step from this step's register set, window
-      // pass TT - 2), this tap's loads are issued behind k-step 1 (the slab of step g + 3 into the same set, window pass TT): every
-      // load has 1.75 taps (~2 us) to land before its wait
-      if (FILL && ks == 0) {
-        if constexpr (P == 0) store_slab_from(1, B0, B1); else store_slab_from(0, C0, C1);
-        if constexpr (TT >= 2 && TT <= NPASS + 1) {
-          if constexpr ((TT & 1) == 0) nxt.write_at(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH, sl, sl_ok);
-          else nxt.write_at(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH, sl2, sl2_ok);
-        }
-      }
-      if (FILL && ks == 1) {
-        if constexpr (P == 0) load_slab_into(B0, B1); else load_slab_into(C0, C1);
-        if constexpr (TT < NPASS) {
-          if constexpr ((TT & 1) == 0) sl = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl_ok);
-          else sl2 = nxt.load_at(phy[TT], phx[TT], true, n_gy0, n_gx0, 1, a.IH, a.IW, sl2_ok);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
 
+  // ---- one tap, ILV: sixteen slots of {one MFMA, one fragment read, one piece of the staging code}, each fenced, so that the
+  // staging instructions execute under the MFMA just issued instead of in blocks between the k-steps (see the kernel's header)
+  auto tap_ilv = [&](auto tc, auto spc) __attribute__((always_inline)) {
+    constexpr int TT = decltype(tc)::value;
+    constexpr int SP = decltype(spc)::value;
+    constexpr int P = (TT + SP) & 1;
+    char* awin = ldsA + cb * P3_ABYTES;
+    char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
+    if constexpr (TT == 0) {
+      if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
+      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+    }
+    const int toff = __builtin_amdgcn_readlane(v_toff, TT);
+    constexpr int R0 = TT % 3;
+    const char* bsl = ldsB + (TT % 3) * SLAB;
+    const int toff_n = __builtin_amdgcn_readlane(v_toff, TT == 8 ? 0 : TT + 1);
+    const char* awin_n = TT == 8 ? anext : awin;
+    const char* bsl_n = ldsB + ((TT + 1) % 3) * SLAB;
+    constexpr bool WST = TT >= 2 && TT <= NPASS + 1;   // the window slice loaded two taps ago goes to LDS
+    constexpr bool WLD = TT < NPASS;                   // window pass TT is loaded
+    uint4& wsl = (TT & 1) == 0 ? sl : sl2;
+    bool& wok = (TT & 1) == 0 ? sl_ok : sl2_ok;
+    uint4& sb0 = P == 0 ? B0 : C0;
+    uint4& sb1 = P == 0 ? B1 : C1;
+    unsigned wv[4] = {0u, 0u, 0u, 0u};
+    const char* wptr = nullptr;
+    bool wok_new = false;
+    auto slot = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int ks = I / 4, mt = (I % 4) / 2, nt = I % 2, j = I % 4;
+      __builtin_amdgcn_sched_barrier(0);
+      Tr<T>::mma(af[(R0 + ks) % 3][mt], bf[(R0 + ks) % 3][nt], acc[mt][nt]);
+      {   // one fragment of k-step ks + 2 (of the next tap past the end of this one)
+        constexpr int k2 = (ks + 2) % KSTEPS, buf = (R0 + ks + 2) % 3;
+        const char* win = ks + 2 < KSTEPS ? awin : awin_n;
+        const int tf = ks + 2 < KSTEPS ? toff : toff_n;
+        const char* bs = ks + 2 < KSTEPS ? bsl : bsl_n;
+        if constexpr (j < 2) af[buf][j] = *(const uint4*)(win + abase[j] + tf + k2 * 32);
+        else bf[buf][j - 2] = *(const uint4*)(bs + bbase[j - 2] + (((k2 * 2 + h) ^ bswz) * 16));
+      }
+      if constexpr (I == 0) *(uint4*)(ldsB + ((TT + 2) % 3) * SLAB + tid * 16) = sb0;
+      if constexpr (I == 1) *(uint4*)(ldsB + ((TT + 2) % 3) * SLAB + tid * 16 + 8192) = sb1;
+      if constexpr (WST && I >= 2 && I <= 5) {
+        constexpr int k = I - 2;
+        const unsigned w = k == 0 ? wsl.x : k == 1 ? wsl.y : k == 2 ? wsl.z : wsl.w;
+        wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
+      }
+      if constexpr (WST && I == 6) {
+        const uint4 v = wok ? make_uint4(wv[0], wv[1], wv[2], wv[3]) : make_uint4(0, 0, 0, 0);
+        *(uint4*)(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH + nxt.cv * 16) = v;
+      }
+      if constexpr (I == 7) load_slab_ct(std::integral_constant<int, (TT + 4) % 9>{}, sb0, sb1);
+      if constexpr (WLD && I == 8) wptr = nxt.addr_at(pass_y(TT), pass_x(TT), true, n_gy0, n_gx0, 1, a.IH, a.IW, wok_new);
+      if constexpr (WLD && I == 9) { wsl = *(const uint4*)wptr; wok = wok_new; }
+    };
+#define P3_SLOT(i) slot(std::integral_constant<int, i>{})
+    P3_SLOT(0); P3_SLOT(1); P3_SLOT(2); P3_SLOT(3); P3_SLOT(4); P3_SLOT(5); P3_SLOT(6); P3_SLOT(7);
+    P3_SLOT(8); P3_SLOT(9); P3_SLOT(10); P3_SLOT(11); P3_SLOT(12); P3_SLOT(13); P3_SLOT(14); P3_SLOT(15);
+#undef P3_SLOT
+    __builtin_amdgcn_sched_barrier(0);
+    // LDS operations retire in order: everything but the four fragment reads of slots 12..15 has landed (this wave's LDS stores of
+    // slots 0, 1 and 6 included), those four stay in flight across the barrier -- they read what an earlier barrier published
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   auto chunk_body = [&](auto spc) __attribute__((always_inline)) {
-    tap(std::integral_constant<int, 0>{}, spc); tap(std::integral_constant<int, 1>{}, spc); tap(std::integral_constant<int, 2>{}, spc);
-    tap(std::integral_constant<int, 3>{}, spc); tap(std::integral_constant<int, 4>{}, spc); tap(std::integral_constant<int, 5>{}, spc);
-    tap(std::integral_constant<int, 6>{}, spc); tap(std::integral_constant<int, 7>{}, spc); tap(std::integral_constant<int, 8>{}, spc);
+    auto one = [&](auto tc) __attribute__((always_inline)) {
+      if constexpr (ILV) tap_ilv(tc, spc); else tap(tc, spc);
+    };
+    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+    one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+    one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
     if (chunk + 1 < nchunks) { ++chunk; }
     else {
       epilogue(ldsA + cb * P3_ABYTES);
@@ -371,7 +457,7 @@ static P3Geom p3_geom(const ConvArgs& a) {
   g.n_nt = (a.Cout + P3_BN - 1) / P3_BN;
   g.nitems = g.n_mt * g.n_nt;
   g.G = g.nitems < 256 ? g.nitems : 256;   // one workgroup per CU (gfx950 / MI355X only build)
-  g.lds = (size_t)2 * P3_ABYTES + 2 * P3_SLAB;
+  g.lds = (size_t)2 * P3_ABYTES + 2 * P3_SLAB;   // (+1 slab with ILV, added at launch)
   return g;
 }
 }  // namespace
@@ -398,22 +484,22 @@ bool conv3x3p_eligible(const ConvArgs& a, int dtype) {
 
 int conv3x3p_rows(const ConvArgs& a) { return p3_geom(a).n_mt; }
 
-template <typename T, bool FILL>
+template <typename T, bool ILV>
 static hipError_t p3_launch_k(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
   static bool set = false;
   if (!set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<T, FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<T, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     set = true;
   }
-  hipLaunchKernelGGL((conv3x3p_kernel<T, FILL>), dim3(g.G), dim3(P3_NTHREADS), g.lds, st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems);
+  hipLaunchKernelGGL((conv3x3p_kernel<T, ILV>), dim3(g.G), dim3(P3_NTHREADS), g.lds + (ILV ? P3_SLAB : 0), st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems);
   return hipGetLastError();
 }
 template <typename T>
 static hipError_t p3_launch(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
-  static const bool head = getenv("OCTSEG_P3_HEAD") != nullptr;   // A/B switch: loads / stores at the head of the tap
-  if (std::is_same<T, f16_t>::value) return p3_launch_k<T, false>(a, g, st);   // (the deep variant's f16 instantiation spills 5 registers)
-  return head ? p3_launch_k<T, false>(a, g, st) : p3_launch_k<T, true>(a, g, st);
+  static const bool plain = getenv("OCTSEG_P3_PLAIN") != nullptr;   // A/B switch: the head-of-tap variant
+  if constexpr (std::is_same<T, f16_t>::value) return p3_launch_k<T, false>(a, g, st);   // (the interleaved variant's f16 instantiation spills)
+  else return plain ? p3_launch_k<T, false>(a, g, st) : p3_launch_k<T, true>(a, g, st);
 }
 
 hipError_t launch_conv3x3p(int dtype, const ConvArgs& a0, hipStream_t st) {

@@ -61,20 +61,21 @@ template <> struct Tr<bf16_t> {
   // rounding keeps the sign, so max(round(x), 0) == round(max(x, 0)) bit for bit; floor -32768 = no ReLU).
   // (The scalar form -- fma, max, select, convert, shift, or per channel -- cost 2.5x the instructions, and the
   // 1x1 loops were bound by exactly these: 400 vector instructions per 16 MFMAs.)
-  static __device__ __forceinline__ uint4 affine_floor(uint4 v, const float* sc, const float* sh, unsigned floor16) {
+  static __device__ __forceinline__ unsigned affine_floor1(unsigned w, float s0, float s1, float t0, float t1, unsigned floor16) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+    f32x2_t x = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    const f32x2_t s2 = {s0, s1}, t2 = {t0, t1};
+    x = __builtin_elementwise_fma(x, s2, t2);
+    const bf16x2_t b = __builtin_convertvector(x, bf16x2_t);
+    const s16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, b), __builtin_bit_cast(s16x2_t, floor16));
+    return __builtin_bit_cast(unsigned, m);
+  }
+  static __device__ __forceinline__ uint4 affine_floor(uint4 v, const float* sc, const float* sh, unsigned floor16) {
     unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x2_t x = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
-      const f32x2_t s2 = {sc[2 * i], sc[2 * i + 1]}, t2 = {sh[2 * i], sh[2 * i + 1]};
-      x = __builtin_elementwise_fma(x, s2, t2);
-      const bf16x2_t b = __builtin_convertvector(x, bf16x2_t);
-      const s16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, b), __builtin_bit_cast(s16x2_t, floor16));
-      w[i] = __builtin_bit_cast(unsigned, m);
-    }
+    for (int i = 0; i < 4; ++i) w[i] = affine_floor1(w[i], sc[2 * i], sc[2 * i + 1], sh[2 * i], sh[2 * i + 1], floor16);
     return make_uint4(w[0], w[1], w[2], w[3]);
   }
   static __device__ __forceinline__ uint4 affine(uint4 v, const float* sc, const float* sh, int relu) {
@@ -122,16 +123,17 @@ template <> struct Tr<f16_t> {
   }
   static __device__ __forceinline__ unsigned short bits16(float v) { const _Float16 x = (_Float16)v; return __builtin_bit_cast(unsigned short, x); }
   // relu?(x * scale + shift) on 8 channels; floor16 = 0: ReLU (v_pk_max_f16 on the rounded pair), anything else: none
+  static __device__ __forceinline__ unsigned affine_floor1(unsigned w, float s0, float s1, float t0, float t1, unsigned floor16) {
+    const f16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
+    const float l = fmaf(lo(w), s0, t0), h = fmaf(hi(w), s1, t1);
+    f16x2_t p = {(_Float16)l, (_Float16)h};
+    if (floor16 == 0u) p = __builtin_elementwise_max(p, zero);
+    return __builtin_bit_cast(unsigned, p);
+  }
   static __device__ __forceinline__ uint4 affine_floor(uint4 v, const float* sc, const float* sh, unsigned floor16) {
     unsigned w[4] = {v.x, v.y, v.z, v.w};
-    const f16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float l = fmaf(lo(w[i]), sc[2 * i], sh[2 * i]), h = fmaf(hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
-      f16x2_t p = {(_Float16)l, (_Float16)h};
-      if (floor16 == 0u) p = __builtin_elementwise_max(p, zero);
-      w[i] = __builtin_bit_cast(unsigned, p);
-    }
+    for (int i = 0; i < 4; ++i) w[i] = affine_floor1(w[i], sc[2 * i], sc[2 * i + 1], sh[2 * i], sh[2 * i + 1], floor16);
     return make_uint4(w[0], w[1], w[2], w[3]);
   }
   static __device__ __forceinline__ uint4 affine(uint4 v, const float* sc, const float* sh, int relu) {
@@ -238,6 +240,7 @@ struct WindowStager {
   SrcSel s;
   float sc[VEC], sh[VEC];
   bool cvalid, has_aff;
+  unsigned fl16;          // packed 16-bit floor of write_at_nb: 0 = ReLU, 0x80008000 = none
   int cv, p0;
   const char* img_base;   // source pointer of (image n, this thread's channel vector): set by bind_image()
   int row_bytes, pix_bytes;
@@ -284,6 +287,13 @@ struct WindowStager {
     if (!ok) v = make_uint4(0, 0, 0, 0);
     *(uint4*)(lds_row + cv * 16) = v;
   }
+  // write_at without the branch on has_aff (16-bit types): the identity transform is applied instead, so that the whole tap of
+  // conv3x3p is one basic block the scheduler can interleave with the MFMAs
+  __device__ __forceinline__ void write_at_nb(char* lds_row, uint4 v, bool ok) const {
+    v = Tr<T>::affine_floor(v, sc, sh, fl16);
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    *(uint4*)(lds_row + cv * 16) = v;
+  }
   // uniform (host: every source starts on a K-chunk boundary): the chunk lies in ONE source, which is then picked on
   // the scalar unit; otherwise every lane selects for its own channel (4 x 12 vector selects per call)
   // select(): source, channel vector and validity of this thread for `chunk` -- no memory access
@@ -299,6 +309,7 @@ struct WindowStager {
       s = select_src(src, nsrc, cvalid ? c : 0);
     }
     has_aff = cvalid && s.scale != nullptr;
+    fl16 = (has_aff && s.relu) ? 0u : 0x80008000u;
   }
   // setup(): select() + the lazy-BN parameters of the channel vector (plain loads: hipcc waits for them at first use)
   __device__ __forceinline__ void setup(const SrcDesc* src, int nsrc, int Cin, int chunk, int tid, bool uniform = false) {
@@ -308,7 +319,7 @@ struct WindowStager {
       for (int i = 0; i < VEC; ++i) { sc[i] = s.scale[s.cl + i]; sh[i] = s.shift[s.cl + i]; }
     } else {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+      for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = -0.f; }   // (x * 1 + -0 == x bit for bit, -0 included: write_at_nb)
     }
   }
   // Branch-free: the address is clamped into the tensor so the load is unconditional (the compiler can

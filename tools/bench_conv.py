@@ -3,6 +3,10 @@ usage: bench_conv.py N H W Cin Cout R [stride] [mode=fwd|dgrad|wgrad] [iters]"""
 import sys
 sys.path.insert(0, '.')
 import torch
+import os
+if os.environ.get('OCTSEG_LIB'):   # an experimental build of the library (timing experiments)
+    from oct_segmentation_amd import _lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ['OCTSEG_LIB'])
 from oct_segmentation_amd import ops
 
 N, H, W, Cin, Cout, R = map(int, sys.argv[1:7])
@@ -15,6 +19,11 @@ x = torch.randn(N, H, W, Cin, device=dev).bfloat16()
 w = torch.randn(R, R, Cout, Cin, device=dev) * 0.05
 OH = (H + 2 * pad - R) // stride + 1
 dy = torch.randn(N, OH, OH, Cout, device=dev).bfloat16()
+import os
+if os.environ.get('DATA') == 'zeros':      # DVFS probe: no operand toggling in the MFMA pipe
+    x.zero_(); w.zero_(); dy.zero_()
+elif os.environ.get('DATA') == 'ones':
+    x.fill_(1); w.fill_(1); dy.fill_(1)
 def run():
     if mode == 'fwd':
         return ops.conv2d_forward(x, w, None, stride, pad)
