@@ -425,6 +425,9 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                'granted_clock': {'sclk_mhz': 1947, 'quoted_mhz': 2400, 'frac_at_granted_clock': round(ach / (peak * 1947 / 2400), 4),
+                                  'note': 'the 3x3 loops run on the 1400 W package limit: 1391 W at 1947 MHz on random operands, 1094 W at 2398 MHz '
+                                          'on zeros (profiles/r2_power_probe.txt, tools/power_probe.sh); `peak` is the 2.4 GHz figure'},
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
                 'kernel_ms_per_step': round(tot_ms / n_alone, 3),

@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, 'oct_segmentation_amd', 'csrc')
 tmp = tempfile.mkdtemp()
 so = os.path.join(tmp, 'liboctseg_stamp.so')
-srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'gemm1x1.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
+srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'conv3x3p.hip', 'gemm1x1.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
 prebuilt = os.path.join(root, 'oct_segmentation_amd', 'liboctseg_stamp.so')   # built in the build container, travels with the snapshot
 if os.path.exists(prebuilt):
     so = prebuilt
