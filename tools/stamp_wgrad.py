@@ -3,7 +3,7 @@ import os, subprocess, sys, shutil, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, 'oct_segmentation_amd', 'csrc')
 tmp = tempfile.mkdtemp(); so = os.path.join(tmp, 'lib.so')
-srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
+srcs = [os.path.join(csrc, f) for f in ('conv_mfma.hip', 'conv3x3p.hip', 'gemm1x1.hip', 'wgrad_mfma.hip', 'elementwise.hip', 'augment.hip', 'plan.cpp')]
 subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17', '-w', '-DOCTSEG_STAMP'] + os.environ.get('OCTSEG_EXTRA_DEFS', '').split() + ['-o', so] + srcs, check=True)
 sys.path.insert(0, root)
 import torch
