@@ -59,7 +59,7 @@ typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
   const char* arch;     /* "unet" | "unetplusplus" | "linknet" (case-insensitive) */
-  const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" */
+  const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
   int classes;          /* output channels */
   int batch, height, width;
   int dtype;            /* octseg_dtype: storage/MFMA input type of activations (accumulate is f32) */

@@ -193,6 +193,19 @@ static void wgrad_launches(const Geom& g, std::vector<WgradArgs>& out) {
 }
 
 // ================================================================ graph builder
+// The side stream carries work that is off the critical chain (weight gradients, the second forward lane).  OCTSEG_SIDE_PRIORITY=low
+// creates it with the lowest stream priority, so that the chain's kernels win the dispatch whenever compute units free up (A/B switch).
+static hipError_t create_side_stream(hipStream_t* st) {
+  static const char* pr = getenv("OCTSEG_SIDE_PRIORITY");
+  if (pr != nullptr && (pr[0] == 'l' || pr[0] == 'h')) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest);
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 static bool serial_mode();
 
 namespace {
@@ -290,10 +303,11 @@ Value mat(int t) { Value v; v.t = t; v.bn = -1; return v; }
 // torchvision ResNet; returns materialised features f1..f5
 std::vector<int> build_resnet(Builder& b, const std::string& enc) {
   octseg_plan* P = b.P;
-  const bool bottleneck = enc == "resnet50" || enc == "resnet101";
+  const bool bottleneck = enc == "resnet50" || enc == "resnet101" || enc == "resnet152";
   int nblocks[4];
   if (enc == "resnet18") { int v[4] = {2, 2, 2, 2}; memcpy(nblocks, v, sizeof v); }
   else if (enc == "resnet34" || enc == "resnet50") { int v[4] = {3, 4, 6, 3}; memcpy(nblocks, v, sizeof v); }
+  else if (enc == "resnet152") { int v[4] = {3, 8, 36, 3}; memcpy(nblocks, v, sizeof v); }
   else { int v[4] = {3, 4, 23, 3}; memcpy(nblocks, v, sizeof v); }
   const int KP = 160;  // 7*7*3 = 147 padded to a multiple of 32
   P->col_tensor = b.tensor(P->B, P->H / 2, P->W / 2, KP, false);
@@ -681,7 +695,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
   hipStream_t lst[2] = {E.st, E.st};
   if (lanes) {
     if (!P->side) {
-      HIPCHK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
+      HIPCHK(create_side_stream(&P->side));
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
     }
@@ -994,7 +1008,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   static const bool no_side = getenv("OCTSEG_NO_SIDE_STREAM") != nullptr;   // A/B switch
   if (!no_side && !serial_mode()) {
     if (!P->side) {
-      HIPCHK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
+      HIPCHK(create_side_stream(&P->side));
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
     }
@@ -1092,8 +1106,8 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   }
   if (d->batch <= 0 || d->classes <= 0 || d->classes > 16) return fail(OCTSEG_BAD_SHAPE, "batch > 0 and 1 <= classes <= 16 required");
   const std::string enc = lower(d->encoder);
-  if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101")
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101)");
+  if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101" && enc != "resnet152")
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152)");
   octseg_plan* P = new octseg_plan();
   P->arch = lower(d->arch); P->encoder = enc; P->classes = d->classes;
   P->B = d->batch; P->H = d->height; P->W = d->width; P->dtype = d->dtype;

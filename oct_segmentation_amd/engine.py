@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib as L
 
 _ARCHS = ('unet', 'unetplusplus', 'linknet')
-_ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101')
+_ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152')
 
 
 def get_preprocessing_params(encoder_name, pretrained='imagenet'):

@@ -26,12 +26,14 @@ ENCODER_CHANNELS = {
     'resnet34': (3, 64, 64, 128, 256, 512),
     'resnet50': (3, 64, 256, 512, 1024, 2048),
     'resnet101': (3, 64, 256, 512, 1024, 2048),
+    'resnet152': (3, 64, 256, 512, 1024, 2048),
 }
 _RESNET_CFG = {
     'resnet18': ('basic', (2, 2, 2, 2)),
     'resnet34': ('basic', (3, 4, 6, 3)),
     'resnet50': ('bottleneck', (3, 4, 6, 3)),
     'resnet101': ('bottleneck', (3, 4, 23, 3)),
+    'resnet152': ('bottleneck', (3, 8, 36, 3)),
 }
 
 

@@ -51,7 +51,7 @@ def _build(k, arch, enc, classes, residual_safe=False):
     ref = create_model(arch, enc, classes=classes)
     randomize_bn(ref, 100 + k)
     g = torch.Generator().manual_seed(200 + k)
-    last = 'bn3' if enc in ('resnet50', 'resnet101') else 'bn2'
+    last = 'bn3' if enc in ('resnet50', 'resnet101', 'resnet152') else 'bn2'
     with torch.no_grad():
         for name, m in ref.named_modules():
             if isinstance(m, torch.nn.BatchNorm2d):

@@ -16,6 +16,7 @@ NETS = [
     ('unet', 'resnet50', 1, 4, 64),          # Bottleneck path (see DEEP below)
     ('linknet', 'resnet50', 2, 4, 64),
     ('unetplusplus', 'resnet34', 2, 2, 64),
+    ('unet', 'resnet152', 1, 2, 128),        # torchvision Bottleneck [3, 8, 36, 3]: the family's deepest member (150 BN layers)
 ]
 
 
@@ -24,7 +25,10 @@ NETS = [
 # which widens the band of ReLU pre-activations whose sign can differ: kink-free seeds do not exist in
 # practice.  Bottleneck nets are therefore held to 2e-4 on logits and to the cosine criterion only;
 # their kernels are pinned individually in test_gpu_ops.py and the shared graph code by the r18/r34 nets.
-DEEP = ('resnet50', 'resnet101')
+DEEP = ('resnet50', 'resnet101', 'resnet152')
+# the forward band of a net WITH ReLU kinks grows with its depth: resnet152 (150 BN layers) measures 4.3e-4 of the logit scale here while its
+# kink-free run agrees to 2e-6 with gradient cosine 1.0 -- flipped ReLU masks, not arithmetic
+FWD_TOL = {'resnet50': 2e-4, 'resnet101': 2e-4, 'resnet152': 8e-4}
 
 
 def _oracle(arch, enc, classes, seed=7, kinkfree=False):
@@ -103,7 +107,7 @@ def test_train_step_parity_fp32(cuda, cfg):
         scale = logits_ref.abs().max().item()
         err = (lg - logits_ref).abs().max().item()
         print(f'{cfg} seed {seed}: logits max|d|={err:.3e} (scale {scale:.3e}) loss {loss.item():.7f} vs {loss_ref.item():.7f}')
-        tol = (2e-4 if enc in DEEP else 1e-4) * max(1.0, scale)
+        tol = FWD_TOL.get(enc, 1e-4) * max(1.0, scale)
         assert err <= tol
         assert abs(loss.item() - loss_ref.item()) <= 1e-5
         # thresholded masks: bit-exact except where the oracle's logit is within the fp32 parity band of 0
@@ -117,12 +121,12 @@ def test_train_step_parity_fp32(cuda, cfg):
         for k, v in sd_ref.items():
             if k.endswith('running_mean') or k.endswith('running_var'):
                 worst = max(worst, (sd[k].cpu() - v).abs().max().item() / max(1.0, v.abs().max().item()))
-        assert worst < (2e-4 if enc in DEEP else 1e-4), f'running stats {worst}'
+        assert worst < FWD_TOL.get(enc, 1e-4), f'running stats {worst}'
         cos, worst_g, name = _grad_report(net.named_grads(), ref)
         print(f'{cfg} seed {seed}: grad cosine {cos:.7f} worst per-param err {worst_g:.3e} ({name})')
         # a handful of ReLU masks flip between any two fp32 implementations of a 50-layer net:
         # the strict gradient check is test_gradients_kinkfree_fp32, this one only guards against gross errors
-        assert cos >= (0.995 if enc in DEEP else 0.999)
+        assert cos >= (0.99 if enc == 'resnet152' else 0.995 if enc in DEEP else 0.999)   # (resnet152 measures 0.9951 / 0.9960)
 
 
 @pytest.mark.parametrize('cfg', NETS, ids=['-'.join(map(str, c)) for c in NETS])

@@ -34,7 +34,8 @@ def _plan(arch, enc, classes, B, H, W, dt=L.BF16):
 
 @pytest.mark.parametrize('arch,enc,classes,S,gmac', [
     ('unet', 'resnet18', 1, 256, 5.40), ('unetplusplus', 'resnet101', 1, 704, 471.07), ('linknet', 'resnet50', 2, 704, 54.99),
-    ('unet', 'resnet50', 1, 704, 80.41), ('unetplusplus', 'resnet34', 1, 704, 139.03), ('linknet', 'resnet18', 2, 704, 19.78)])
+    ('unet', 'resnet50', 1, 704, 80.41), ('unetplusplus', 'resnet34', 1, 704, 139.03), ('linknet', 'resnet18', 2, 704, 19.78),
+    ('unet', 'resnet152', 1, 704, 153.74)])   # (resnet152: torchvision 11.51 GMAC @224^2 -> x9.88 at 704^2, + the U-Net/r50 decoder)
 def test_graph_matches_oracle_tree_and_survey_macs(arch, enc, classes, S, gmac):
     from oracle import create_model
     lib = L.lib()
