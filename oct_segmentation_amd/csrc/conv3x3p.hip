@@ -119,6 +119,23 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+  // ILV computes the same 64 x 64 wave tile with v_mfma_f32_16x16x32 (4 x 4 blocks of 16 x 16, 32 channels per MFMA): block row mb = tile row
+  // wm * 4 + mb, lane & 15 = pixel of the row (A) / output channel of the block (B), lane >> 4 = 16-byte slice of the 64-byte k-step
+  constexpr bool M16 = ILV;
+  f32x4_t acc16[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc16[i][j][k] = 0.f;
+  const int r16 = lane & 15, g16 = lane >> 4;
+  int abase16[4], bbase16[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) abase16[mb] = ((wm * 4 + mb) * RW + r16) * PITCH + g16 * 16;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bbase16[nb] = (wn * NT * 32 + nb * 16 + r16) * RB;
+  const int bswz16 = (r16 >> 1) & (VPR - 1);   // (block rows differ by multiples of 16: the same swizzle)
 
   // ---- weight slab cursor: two steps ahead of the consumer
   const char* Wp = (const char*)a.W;
@@ -200,7 +217,19 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bf[buf][nt] = *(const uint4*)(bsl + bbase[nt] + (((ks * 2 + h) ^ bswz) * 16));
   };
-  if constexpr (ILV) {
+  // M16: A fragments of the current k-step (one set, each replaced in place behind its last MFMA), B fragments of this and the next one
+  uint4 fa[4], fb[2][4];
+  auto ldA16 = [&](int mb, const char* win, int toff, int kq) __attribute__((always_inline)) {
+    fa[mb] = *(const uint4*)(win + abase16[mb] + toff + kq * 64);
+  };
+  auto ldB16 = [&](int set, int nb, const char* bsl, int kq) __attribute__((always_inline)) {
+    fb[set][nb] = *(const uint4*)(bsl + bbase16[nb] + (((kq * 4 + g16) ^ bswz16) * 16));
+  };
+  if constexpr (M16) {
+    const int t0 = __builtin_amdgcn_readlane(v_toff, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ldA16(i, ldsA, t0, 0); ldB16(0, i, ldsB, 0); }
+  } else if constexpr (ILV) {
     const int t0 = __builtin_amdgcn_readlane(v_toff, 0);
     frag_load(0, ldsA, t0, ldsB, 0);
     frag_load(1, ldsA, t0, ldsB, 1);
@@ -223,6 +252,13 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       const int co = co0 + wn * NT * 32 + nt * 32 + r;
       bias[nt] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
     }
+    float bias16[4], t1[4], t2[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int co = co0 + wn * NT * 32 + nb * 16 + r16;
+      bias16[nb] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+      t1[nb] = 0.f; t2[nb] = 0.f;
+    }
     const float ofloor = a.relu_out ? 0.f : -3.0e38f;
     // this thread's share of the store sweep: channel vector cvv, pixel (rloc, tx) of every wave-row group
     const int cvv = tid & 15, tx = (tid >> 4) & 15, rloc = tid >> 8;
@@ -239,6 +275,20 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       // transposed half tile into LDS
+      if constexpr (M16) {
+#pragma unroll
+        for (int rl = 0; rl < 2; ++rl)       // row of the strip = block row 2 * mt + rl
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float val = fmaxf(acc16[2 * mt + rl][nb][j] + bias16[nb], ofloor);
+              t1[nb] += val; t2[nb] += val * val;
+              acc16[2 * mt + rl][nb][j] = 0.f;
+              const int q = wm * 32 + rl * 16 + 4 * g16 + j;
+              *(unsigned short*)(otile + q * OPITCH + (wn * NT * 32 + nb * 16 + r16) * 2) = Tr<T>::bits16(val);
+            }
+      } else
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -302,7 +352,20 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       }
       __syncthreads();   // the half tile is consumed before the next half (or the next chunk's window slices) overwrites it
     }
+    if (M16 && a.stat_slab != nullptr) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {   // the four lanes that share lane & 15 hold different pixels of one channel
+        t1[nb] += __shfl_xor(t1[nb], 16); t1[nb] += __shfl_xor(t1[nb], 32);
+        t2[nb] += __shfl_xor(t2[nb], 16); t2[nb] += __shfl_xor(t2[nb], 32);
+        if (g16 == 0) {
+          const int cl = wn * NT * 32 + nb * 16 + r16;
+          red[(wm * BN + cl) * 2 + 0] = t1[nb];
+          red[(wm * BN + cl) * 2 + 1] = t2[nb];
+        }
+      }
+    }
     if (a.stat_slab != nullptr) {
+      if constexpr (!M16)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         s1[nt] += __shfl_xor(s1[nt], 32);
@@ -357,6 +420,79 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+  };
+
+  // ---- one tap with v_mfma_f32_16x16x32 (M16): two k-steps of 16 MFMAs (block row major), 32 fenced slots.  Slot I = MFMA (mb, nb) of
+  // k-step kq.  Behind it: slots 0, 1, 2, 4 of a k-step request the B fragments of the NEXT k-step (other set), slots 3, 7, 11, 15 the next
+  // k-step's A fragment of the block row whose last MFMA was just issued (in place); the staging pieces sit in the other slots.
+  auto tap16 = [&](auto tc, auto spc) __attribute__((always_inline)) {
+    constexpr int TT = decltype(tc)::value;
+    constexpr int SP = decltype(spc)::value;
+    constexpr int P = (TT + SP) & 1;
+    char* awin = ldsA + cb * P3_ABYTES;
+    char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
+    if constexpr (TT == 0) {
+      if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
+      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+    }
+    const int toff = __builtin_amdgcn_readlane(v_toff, TT);
+    const char* bsl = ldsB + (TT % 3) * SLAB;
+    const int toff_n = __builtin_amdgcn_readlane(v_toff, TT == 8 ? 0 : TT + 1);
+    const char* awin_n = TT == 8 ? anext : awin;
+    const char* bsl_n = ldsB + ((TT + 1) % 3) * SLAB;
+    constexpr bool WST = TT >= 2 && TT <= NPASS + 1;
+    constexpr bool WLD = TT < NPASS;
+    uint4& wsl = (TT & 1) == 0 ? sl : sl2;
+    bool& wok = (TT & 1) == 0 ? sl_ok : sl2_ok;
+    uint4& sb0 = P == 0 ? B0 : C0;
+    uint4& sb1 = P == 0 ? B1 : C1;
+    unsigned wv[4] = {0u, 0u, 0u, 0u};
+    const char* wptr = nullptr;
+    bool wok_new = false;
+    auto slot = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int kq = I / 16, mb = (I % 16) / 4, nb = I % 4, J = I % 16;
+      __builtin_amdgcn_sched_barrier(0);
+      Tr<T>::mma16(fa[mb], fb[kq][nb], acc16[mb][nb]);
+      {   // fragments of the next k-step: k-step 1 of this tap, or k-step 0 of the next one
+        const char* win = kq == 0 ? awin : awin_n;
+        const int tf = kq == 0 ? toff : toff_n;
+        const char* bs = kq == 0 ? bsl : bsl_n;
+        constexpr int kn = kq ^ 1;
+        if constexpr (J == 0) ldB16(kn, 0, bs, kn);
+        if constexpr (J == 1) ldB16(kn, 1, bs, kn);
+        if constexpr (J == 2) ldB16(kn, 2, bs, kn);
+        if constexpr (J == 4) ldB16(kn, 3, bs, kn);
+        if constexpr (J % 4 == 3) ldA16(mb, win, tf, kn);
+      }
+      if constexpr (I == 5) *(uint4*)(ldsB + ((TT + 2) % 3) * SLAB + tid * 16) = sb0;
+      if constexpr (I == 6) *(uint4*)(ldsB + ((TT + 2) % 3) * SLAB + tid * 16 + 8192) = sb1;
+      if constexpr (WST && (I == 8 || I == 9 || I == 10 || I == 12)) {
+        constexpr int k = I == 12 ? 3 : I - 8;
+        const unsigned w = k == 0 ? wsl.x : k == 1 ? wsl.y : k == 2 ? wsl.z : wsl.w;
+        wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
+      }
+      if constexpr (WST && I == 13) {
+        const uint4 v = wok ? make_uint4(wv[0], wv[1], wv[2], wv[3]) : make_uint4(0, 0, 0, 0);
+        *(uint4*)(anext + ((TT - 2) * P3_PSTEP + p0w) * PITCH + nxt.cv * 16) = v;
+      }
+      if constexpr (I == 21) load_slab_ct(std::integral_constant<int, (TT + 4) % 9>{}, sb0, sb1);
+      if constexpr (WLD && I == 24) wptr = nxt.addr_at(pass_y(TT), pass_x(TT), true, n_gy0, n_gx0, 1, a.IH, a.IW, wok_new);
+      if constexpr (WLD && I == 25) { wsl = *(const uint4*)wptr; wok = wok_new; }
+    };
+#define P3_SLOT(i) slot(std::integral_constant<int, i>{})
+    P3_SLOT(0); P3_SLOT(1); P3_SLOT(2); P3_SLOT(3); P3_SLOT(4); P3_SLOT(5); P3_SLOT(6); P3_SLOT(7);
+    P3_SLOT(8); P3_SLOT(9); P3_SLOT(10); P3_SLOT(11); P3_SLOT(12); P3_SLOT(13); P3_SLOT(14); P3_SLOT(15);
+    P3_SLOT(16); P3_SLOT(17); P3_SLOT(18); P3_SLOT(19); P3_SLOT(20); P3_SLOT(21); P3_SLOT(22); P3_SLOT(23);
+    P3_SLOT(24); P3_SLOT(25); P3_SLOT(26); P3_SLOT(27); P3_SLOT(28); P3_SLOT(29); P3_SLOT(30); P3_SLOT(31);
+#undef P3_SLOT
+    __builtin_amdgcn_sched_barrier(0);
+    // LDS operations retire in order: the LDS stores of slots 5, 6 and 13 are older than the eight fragment reads of the second k-step;
+    // the two youngest of those (block rows 2 and 3 of the next tap, slots 27 and 31) stay in flight across the barrier
+    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- one tap, ILV: sixteen slots of {one MFMA, one fragment read, one piece of the staging code}, each fenced, so that the
@@ -429,7 +565,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 
   auto chunk_body = [&](auto spc) __attribute__((always_inline)) {
     auto one = [&](auto tc) __attribute__((always_inline)) {
-      if constexpr (ILV) tap_ilv(tc, spc); else tap(tc, spc);
+      if constexpr (M16) tap16(tc, spc); else if constexpr (ILV) tap_ilv(tc, spc); else tap(tc, spc);
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
     one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
