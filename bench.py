@@ -195,6 +195,8 @@ def bench_ensemble(args):
     HBM.  Replayed hipGraphs unless --no-graph."""
     import ctypes as C
     from oct_segmentation_amd import _lib as L
+    if os.environ.get('OCTSEG_LIB'):   # A/B of two builds of the library on one box (tools/ab_perf.sh); the default is the in-tree build
+        L.LIB_PATH = os.path.abspath(os.environ['OCTSEG_LIB'])
     from oct_segmentation_amd.engine import SegNet
     from oct_segmentation_amd.model import CLASS_IDS
     from oct_segmentation_amd.predict import MODELS_META, cv2_nearest_index
@@ -312,6 +314,8 @@ def main():
             dist.init_process_group(args.backend)
 
     from oct_segmentation_amd import _lib as L
+    if os.environ.get('OCTSEG_LIB'):   # A/B of two builds of the library on one box (tools/ab_perf.sh); the default is the in-tree build
+        L.LIB_PATH = os.path.abspath(os.environ['OCTSEG_LIB'])
     from oct_segmentation_amd.model import OCTSegmentationModel
     from oct_segmentation_amd.parallel import GradientExchange, broadcast_buffers, broadcast_parameters, shard_range
     from synth import make_batch
