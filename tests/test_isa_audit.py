@@ -30,8 +30,8 @@ def test_no_instruction_touches_an_asm_load_destination_in_flight():
 
 @pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
 def test_conv3x3p_barrier_leaves_only_fragment_reads_in_flight(tmp_path):
-    """conv3x3p's interleaved tap ends with `s_waitcnt lgkmcnt(4)` + `s_barrier` (hipcc does not model it): the four youngest LGKM operations
-    must be the fragment reads of slots 12..15 in each of its 18 unrolled taps (tools/audit_p3_barrier.py); and the checker itself must
+    """conv3x3p's interleaved tap ends with `s_waitcnt lgkmcnt(N)` + `s_barrier` (hipcc does not model it): the N youngest LGKM operations
+    must be fragment reads in each of its 18 unrolled taps (tools/audit_p3_barrier.py); and the checker itself must
     reject an LDS store moved into that window."""
     csrc = os.path.join(ROOT, 'oct_segmentation_amd', 'csrc')
     isa = os.path.join(csrc, 'build', 'conv3x3p.s')
@@ -51,7 +51,8 @@ def test_conv3x3p_barrier_leaves_only_fragment_reads_in_flight(tmp_path):
         while not lines[i].strip() or lines[i].strip().startswith(';'):
             i += 1
         return lines[i].strip()
-    k = next(i for i, l in enumerate(lines) if l.strip().startswith('s_waitcnt lgkmcnt(4)') and next_ins(i).startswith('s_barrier'))
+    import re
+    k = next(i for i, l in enumerate(lines) if re.match(r's_waitcnt lgkmcnt\([1-9]\)$', l.strip()) and next_ins(i).startswith('s_barrier'))
     j = next(i for i in range(k - 1, 0, -1) if lines[i].strip().startswith('ds_read_b128'))
     lines[j] = '\tds_write_b128 v0, v[0:3]'
     broken = tmp_path / 'broken.s'
