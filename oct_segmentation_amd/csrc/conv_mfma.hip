@@ -1211,7 +1211,11 @@ static Choice choose(const ConvArgs& a, int esz) {
     // (1129 TFLOP/s), 256 -> 256 @176^2 forward 725 -> 622; but 1536 -> 512 @88^2 +12 % and every wide data gradient (K = 64..512,
     // N = 768..3072) +3..14 % slower: one wave per SIMD has nobody to cover the fragment reads at the head of a tap, and the
     // 88^2 grids lose a round.  So: exactly 256 output channels, K >= 256, a grid of >= 1024 workgroups.
-    const bool fits = a.Cout == 256 && a.Cin >= 256 && (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) >= 1024;
+    // ... and not where the persistent kernel takes the layer with the 128-channel tile (16-divisible maps, 2-byte types): on
+    // v_mfma_f32_16x16x32 it beats this 32x32x16 tile (same box: decoder forward 14.0 -> 13.6 ms, data gradients 15.5 -> 15.4)
+    static const bool no_p3 = getenv("OCTSEG_NO_CONV3X3P") != nullptr || getenv("OCTSEG_KEEP_N256") != nullptr;   // A/B switches
+    const bool p3 = !no_p3 && esz == 2 && a.ostride == 1 && a.OH % 16 == 0 && a.OW % 16 == 0 && a.IH == a.OH && a.IW == a.OW;
+    const bool fits = !p3 && a.Cout == 256 && a.Cin >= 256 && (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) >= 1024;
     static const bool all = getenv("OCTSEG_N256_ALL") != nullptr;   // experiments: every >= 256-channel 3x3 layer
     if (!off && (fits || all) && a.ntaps == 9 && a.istride == 1 && a.Cout > 128 && (n256 * 256 - a.Cout) * 10 <= a.Cout && a.Cin > kc) {
       const Variant v{4, 2, 2, 64};   // 2 x 2 waves of (4 M sub-tiles x 4 N sub-tiles)
