@@ -34,6 +34,8 @@ CASES = [
     # persistent 3x3 kernel (conv3x3p.hip, bf16): 512 tiles x 2 N tiles over 256 workgroups = four tiles each, three K chunks with a
     # partial last one (136 = 64 + 64 + 8), a half-empty second N tile; forward and data gradient both walk tiles
     (8, 128, 128, 160, 136, 3, 1, 1, False),
+    # 256 -> 256 on a 16-divisible map: routed to the persistent kernel instead of the wide-N tile (512 items = two per workgroup)
+    (4, 128, 128, 256, 256, 3, 1, 1, False),
 ]
 
 
