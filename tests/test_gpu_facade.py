@@ -186,3 +186,32 @@ def test_stream_schedule_does_not_change_results(cuda):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
     scale = b[3].abs().max().item()
     assert (a[3] - b[3]).abs().max().item() <= 1e-5 * max(scale, 1e-12)
+
+
+def test_validation_step_matches_oracle_eval_forward(cuda):
+    """`validation_step` (model.py:111-132 of the reference): eval-mode forward (running BatchNorm statistics, no update), Dice loss and the
+    per-image metric arrays against the oracle on the same weights and buffers -- loss <= 1e-5, confusion-derived metrics equal."""
+    from oracle import DiceLoss, create_model
+    from oracle.metrics import get_metrics
+    from oracle.nets import randomize_bn
+    m = _model(cuda)
+    ref = create_model('unet', 'resnet18', classes=1)
+    randomize_bn(ref, 3)                      # non-trivial affine parameters AND running statistics
+    m.model.load_state_dict(ref.state_dict())
+    m.eval(); ref.eval()
+    img, mask = make_batch(3, 1, 96, seed=21)
+    before = {k: v.clone() for k, v in m.model.state_dict().items() if 'running_' in k}
+    out = m.validation_step((img.to(cuda), mask.to(cuda)), 0)
+    torch.cuda.synchronize()
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    with torch.no_grad():
+        logits_ref = ref((img - mean) / std)
+        loss_ref = DiceLoss()(logits_ref, mask)
+    assert abs(float(out['val/loss']) - loss_ref.item()) <= 1e-5
+    got = m.validation_step_outputs[-1]
+    exp = get_metrics(mask.long(), (logits_ref.sigmoid() > 0.5).long(), loss_ref)   # the oracle's restatement of utils.py:13-36
+    for k in ('iou', 'dice', 'recall', 'precision', 'f1'):
+        assert np.array_equal(np.asarray(got[k]), np.asarray(exp[k])), k
+    after = {k: v for k, v in m.model.state_dict().items() if 'running_' in k}
+    assert all(torch.equal(before[k], after[k]) for k in before)   # eval: the running statistics are not touched
