@@ -39,7 +39,13 @@ for k in range(n):
     err = (logits.cpu() - z.detach()).abs().max().item(); scale = z.detach().abs().max().item()
     cos, worst, name = _grad_report(net.named_grads(), ref)
     ok = err <= 2e-4 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 1e-5 and cos > 0.999999 and worst < 5e-3
-    if bf16: ok = err <= 3e-2 * max(1, scale) and abs(loss.item() - loss_ref.item()) <= 5e-3 and cos > 0.99
+    if bf16:
+        # yardstick of the test suite (tests/test_gpu_configs.py): what torch's own CPU bf16 autocast loses on the same net and batch --
+        # LinkNet's small logit scales at these sizes put a flat 3 % bound inside bf16 rounding (3.2 .. 4.4 % on some seeds)
+        with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+            za = ref(img).float()
+        err_ac = (za - z.detach()).abs().max().item()
+        ok = err <= max(3e-2 * max(1, scale), 1.5 * err_ac) and abs(loss.item() - loss_ref.item()) <= 5e-3 and cos > 0.99
     bad += 0 if ok else 1
     if only >= 0:
         gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
@@ -52,6 +58,6 @@ for k in range(n):
                          int((d > 0.1 * d.max()).sum()), int(d.argmax())))
         rows.sort(reverse=True)
         for r in rows[:12]: print('   ', r)
-    print(f'{"ok " if ok else "BAD"} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f} loss {abs(loss.item()-loss_ref.item()):.1e} cos {cos:.8f} worst {worst:.1e} ({name})', flush=True)
+    print(f'{"ok " if ok else "BAD"} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f}' + (f' (autocast {err_ac:.1e})' if bf16 else '') + f' loss {abs(loss.item()-loss_ref.item()):.1e} cos {cos:.8f} worst {worst:.1e} ({name})', flush=True)
 print('failures', bad)
 sys.exit(1 if bad else 0)
