@@ -36,6 +36,9 @@ CASES = [
     (8, 128, 128, 160, 136, 3, 1, 1, False),
     # 256 -> 256 on a 16-divisible map: routed to the persistent kernel instead of the wide-N tile (512 items = two per workgroup)
     (4, 128, 128, 256, 256, 3, 1, 1, False),
+    # the wide-N tile (256 output channels, K >= 256, >= 1024 workgroups) where the persistent kernel is not eligible: a 120 x 120 map
+    # (7.5 tiles per side: ragged tiles in both directions)
+    (16, 120, 120, 256, 256, 3, 1, 1, False),
 ]
 
 
