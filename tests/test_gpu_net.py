@@ -162,7 +162,8 @@ def test_eval_forward_and_predict_fp32(cuda, cfg):
     assert err <= 1e-4 * max(1.0, scale)
 
 
-F16_NETS = [('unet', 'resnet18', 1, 2, 64), ('unetplusplus', 'resnet50', 1, 2, 128), ('linknet', 'resnet50', 2, 2, 128), ('unetplusplus', 'resnet101', 1, 1, 128)]
+# (sizes kept small: the yardstick below is a CPU fp16 autocast forward, whose convolutions have no fast path -- 128^2 U-Net++ took 40 s per case)
+F16_NETS = [('unet', 'resnet18', 1, 2, 64), ('unetplusplus', 'resnet50', 1, 1, 96), ('linknet', 'resnet50', 2, 2, 128), ('unetplusplus', 'resnet101', 1, 1, 96)]
 
 
 @pytest.mark.parametrize('cfg', F16_NETS, ids=['-'.join(map(str, c)) for c in F16_NETS])
@@ -186,14 +187,18 @@ def test_eval_forward_f16_serving_dtype(cuda, cfg):
     net.load_state_dict(ref.state_dict())
     with torch.no_grad():
         y_ref = ref(img)
-        try:   # yardstick: torch's own CPU fp16 autocast of the same network, where this torch build has it
-            with torch.autocast('cpu', dtype=torch.float16):
-                err_ac = (ref(img).float() - y_ref).abs().max().item()
-        except Exception:
-            err_ac = 0.0
     y = net(img.to(cuda), normalize=False).cpu()
     scale = y_ref.abs().max().item()
     err = (y - y_ref).abs().max().item()
+    err_ac = 0.0
+    if err > 2e-3 * max(1.0, scale):
+        # yardstick, only where the flat bound does not already hold (CPU fp16 convolutions take ~40 s for the U-Net++ nets): torch's own
+        # CPU fp16 autocast of the same network, where this torch build has it
+        try:
+            with torch.no_grad(), torch.autocast('cpu', dtype=torch.float16):
+                err_ac = (ref(img).float() - y_ref).abs().max().item()
+        except Exception:
+            err_ac = 0.0
     print(f'{cfg}: f16 eval logits max|d|={err:.3e} scale {scale:.3e} ({err / max(scale, 1):.2e} of scale; torch cpu fp16 autocast {err_ac:.3e})')
     assert torch.isfinite(y).all()
     tol = max(2e-3 * max(1.0, scale), 1.5 * err_ac)
