@@ -377,6 +377,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], sc[i], sh[i]) > 0.f)) g[i] = 0.f;
       }
+      if (a.res_grad != nullptr) {   // the masked gradient also flows into the block's identity shortcut (masked_accum's arithmetic)
+        float d[VEC];
+        if (a.res_store) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) d[i] = g[i];
+        } else {
+          EV<T>::unpack(ldv<T>(a.res_grad, v), d);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) d[i] += g[i];
+        }
+        stv<T>(a.res_grad, v, EV<T>::pack(d));
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float xh = (y[i] - mu[i]) * rs[i];

@@ -74,7 +74,9 @@ struct BnBwdArgs {
   float* coef;                           // [C][2]: (sum dz / M, sum dz*xhat / M)
   void* dy;                              // pass 3 output (may alias g)
   double* part; unsigned* counters;      // scratch of the two-level slab reduction (pass 2)
-};
+  void* res_grad; int res_store;         // pass 3, optional: the identity shortcut's gradient  res_grad (+)= g * mask  in the same sweep
+};                                       // (what masked_accum would re-read g and the mask source for); res_store = 1: first writer
+
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);

@@ -822,7 +822,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
 }
 
 // BN backward of BN `bn` over raw tensor y: g -> dy (written to grad(y))
-static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out_mask) {
+static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out_mask, void* res_grad = nullptr, int res_store = 0) {
   octseg_plan* P = E.P;
   const BNInfo& b = P->bns[bn];
   const TensorInfo& t = P->tensors[b.y];
@@ -844,6 +844,7 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   a.dbeta = E.grads + P->params[b.beta].off;
   a.coef = E.bn_coef(bn);
   a.dy = E.grad(b.y);
+  a.res_grad = res_grad; a.res_store = res_store;
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
   {
@@ -852,7 +853,7 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   }
   HIPCHK(launch_bn_bwd_finalize(a, E.st));
   {
-    ProfScope ps(3, tbytes * (mask == 2 ? 4 : 3), E.st, b.name + ".bwd_apply");
+    ProfScope ps(3, tbytes * ((mask == 2 ? 4 : 3) + (res_grad ? (res_store ? 1 : 2) : 0)), E.st, b.name + ".bwd_apply");
     HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
   }
   return OCTSEG_OK;
@@ -1049,9 +1050,19 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         const size_t n = (size_t)t.N * t.H * t.W * t.C;
         // main branch: with a post-add the relu mask must come from bn(y) itself
         const int mask = !op.relu ? 0 : (op.post >= 0 ? 1 : 2);
-        rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out));
+        // identity shortcut of a residual block (no BatchNorm on it, ReLU mask from the block's output): its gradient G * mask is
+        // written by the main branch's apply sweep, which holds G and the mask already (was a masked_accum pass of its own)
+        static const bool no_fuse_res = getenv("OCTSEG_NO_FUSED_RESGRAD") != nullptr;   // A/B switch
+        const bool fuse_res = !no_fuse_res && mask == 2 && op.res.t >= 0 && op.res.bn < 0 && P->tensors[op.res.t].need_grad &&
+                              E.grad(op.res.t) != G && E.grad(op.res.t) != E.grad(P->bns[op.y.bn].y);
+        if (fuse_res) {
+          const int acc = E.claim(op.res.t);
+          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out), E.grad(op.res.t), acc ? 0 : 1);
+        } else {
+          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out));
+        }
         if (rc) return rc;
-        if (op.res.t >= 0) {
+        if (op.res.t >= 0 && !fuse_res) {
           if (op.res.bn >= 0) {
             rc = bn_backward(E, op.res.bn, G, op.relu ? 2 : 0, E.act(op.out));
             if (rc) return rc;
