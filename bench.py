@@ -251,11 +251,12 @@ def bench_ensemble(args):
     macs = sum(net.fwd_macs(B, S, S) for net, _ in nets) / B
     ach = prof[1] / (prof[0] * 1e-3) / 1e12 if prof[0] > 0 else 0.0
     peak = 157.3 if args.dtype == 'fp32' else 2500.0
-    out = {'metric': 'OCT frames/sec (704x704, fp16) 3-net ensemble inference', 'value': round(B * args.steps / dt, 3), 'unit': 'frames/s',
+    out = {'metric': f'OCT frames/sec (704x704, {args.dtype}) 3-net ensemble inference', 'value': round(B * args.steps / dt, 3), 'unit': 'frames/s',
            'n_gpus': 1, 'steps': args.steps, 'warmup': max(args.warmup, 3), 'ms_per_step': round(dt / args.steps * 1e3, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
            'data': 'synthetic OCT-shaped frames (seeded), random-init weights',
-           'config': {'workload': f'ensemble LM unetplusplus/resnet101 + FC_LC linknet/resnet50 (2 classes) + VV unet/resnet50, 704x704 -> 4-class '
+           'config': {'multi_gpu': 'replicas only: frames are independent, this workload runs on one GPU', 'fc_lc_forwards_per_batch': 1,   # the reference runs the FC_LC net once per class = twice (predict.py:70-76)
+                      'workload': f'ensemble LM unetplusplus/resnet101 + FC_LC linknet/resnet50 (2 classes) + VV unet/resnet50, 704x704 -> 4-class '
                                   f'1000x1000 masks, batch {B}, eval forward + GPU mask assembly, {"hipGraph replay" if not args.no_graph else "eager launches"}',
                       'global_batch': B, 'parallelism': 'dp1', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel (forward, BatchNorm folded)', 'achieved': round(ach, 2),
@@ -282,6 +283,9 @@ def main():
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)')
+    ap.add_argument('--force-exchange', action='store_true',
+                    help='N = 1: run the data-parallel step anyway -- a one-rank RCCL group, buffer broadcast and the sliced all-reduce '
+                         'beside the backward (exercises the nccl branch on a single GPU; the collectives are identities)')
     args = ap.parse_args()
     if args.workload == 'ensemble_704_fp16':
         args.dtype = args.dtype or 'fp16'
@@ -305,13 +309,17 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in the single-GPU gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    dp = world > 1 or args.force_exchange      # the data-parallel step (process group, buffer broadcast, sliced all-reduce)
+    if dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29531')
+        kw = dict(rank=rank, world_size=world) if world == 1 else {}
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, **kw)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, **kw)
 
     from oct_segmentation_amd import _lib as L
     if os.environ.get('OCTSEG_LIB'):   # A/B of two builds of the library on one box (tools/ab_perf.sh); the default is the in-tree build
@@ -336,7 +344,7 @@ def main():
     model.train()
     net = model.model
     exchange = None
-    if world > 1:
+    if dp:
         broadcast_parameters(net)
         exchange = GradientExchange(net, nslices=args.allreduce_slices)
     opt = model.configure_optimizers()
@@ -344,7 +352,7 @@ def main():
     img, mask = img.to(dev), mask.to(dev)
 
     def step():
-        if world > 1:
+        if dp:
             broadcast_buffers(net)  # torch-DDP broadcast_buffers=True
         # grad_scale 1/world + SUM all-reduce == DDP's gradient mean; the all-reduce runs slice by slice beside the backward
         loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
@@ -353,7 +361,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -429,9 +437,6 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
-                'granted_clock': {'sclk_mhz': 1947, 'quoted_mhz': 2400, 'frac_at_granted_clock': round(ach / (peak * 1947 / 2400), 4),
-                                  'note': 'the 3x3 loops run on the 1400 W package limit: 1391 W at 1947 MHz on random operands, 1094 W at 2398 MHz '
-                                          'on zeros (profiles/r2_power_probe.txt, tools/power_probe.sh); `peak` is the 2.4 GHz figure'},
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
                 'kernel_ms_per_step': round(tot_ms / n_alone, 3),
@@ -451,10 +456,16 @@ def main():
                 },
             },
         }
+        if power and power.get('sclk_mhz'):   # the clock the card granted during the timed steps (sampled, not assumed)
+            mhz = float(power['sclk_mhz'])
+            out['roofline']['granted_clock'] = {
+                'sclk_mhz': mhz, 'quoted_mhz': 2400, 'frac_at_granted_clock': round(ach / (peak * mhz / 2400.0), 4),
+                'note': 'hwmon freq1_input averaged over the timed steps of THIS run (a step alternates power-capped conv loops with HBM '
+                        'sweeps, so the conv loops themselves run below this average); `peak` is the 2.4 GHz figure'}
+        if args.force_exchange:
+            out['config']['force_exchange'] = f'one-rank {args.backend} group: buffer broadcast + {args.allreduce_slices}-slice all-reduce issued beside the backward'
         # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)
-        tpath = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r{k}_traffic.json') for k in (3, 2, 1)) if os.path.exists(q)), '')
         if os.path.exists(tpath) and args.workload == 'unetpp_r101_704' and B == 16 and args.dtype == 'bf16':
             try:
                 out['roofline']['traffic'] = round(json.load(open(tpath))['mfma_family']['hbm_bytes_per_launch'])
@@ -475,7 +486,7 @@ def main():
             note('CPU baseline (oracle, 2 frames per step, fp32 + bf16 autocast) ...')
             out['cpu_baseline'] = cpu_baseline(arch, enc, classes, S)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         torch.distributed.destroy_process_group()
 
 

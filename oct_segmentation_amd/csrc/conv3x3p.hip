@@ -259,7 +259,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       bias16[nb] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
       t1[nb] = 0.f; t2[nb] = 0.f;
     }
-    const float ofloor = a.relu_out ? 0.f : -3.0e38f;
+    const float ofloor = a.relu_out ? 0.f : NO_FLOOR;
     // this thread's share of the store sweep: channel vector cvv, pixel (rloc, tx) of every wave-row group
     const int cvv = tid & 15, tx = (tid >> 4) & 15, rloc = tid >> 8;
     const int cov = co0 + cvv * 8;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
           for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float val = fmaxf(acc16[2 * mt + rl][nb][j] + bias16[nb], ofloor);
+              float val = clamp_lo(acc16[2 * mt + rl][nb][j] + bias16[nb], ofloor);
               t1[nb] += val; t2[nb] += val * val;
               acc16[2 * mt + rl][nb][j] = 0.f;
               const int q = wm * 32 + rl * 16 + 4 * g16 + j;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float val = fmaxf(acc[mt][nt][i] + bias[nt], ofloor);
+          float val = clamp_lo(acc[mt][nt][i] + bias[nt], ofloor);
           s1[nt] += val; s2[nt] += val * val;
           acc[mt][nt][i] = 0.f;
           const int rl = h ^ ((0x6 >> (i >> 2)) & 1);     // grouped row map: row of the strip, column 4 * (i >> 2) + (i & 3)

@@ -11,6 +11,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int TW = 16;                // output-grid tile width (pixels)
 constexpr int NTHR = 256;
 
+// max(v, lo) that keeps a NaN a NaN (fmaxf / v_max_f32 return the OTHER operand, so a diverged accumulator would come out as 0 -- or as
+// -FLT_MAX without a ReLU -- where torch's relu / plain store propagate it) and, with lo = -inf for "no ReLU", leaves -inf alone
+static __device__ __forceinline__ float clamp_lo(float v, float lo) { return v < lo ? lo : v; }
+constexpr float NO_FLOOR = -__builtin_inff();
+
 template <typename T> struct Tr;
 template <> struct Tr<float> {
   static constexpr int VEC = 4;  // channels per 16-byte vector
@@ -26,15 +31,15 @@ template <> struct Tr<float> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       x[i] = fmaf(x[i], sc[i], sh[i]);
-      if (relu) x[i] = fmaxf(x[i], 0.f);
+      if (relu) x[i] = clamp_lo(x[i], 0.f);
     }
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
   }
-  // branch-free form: max(x*scale+shift, lo), lo = 0 (ReLU) or -FLT_MAX (none)
+  // branch-free form: max(x*scale+shift, lo), lo = 0 (ReLU) or anything below zero (none: taken as -inf)
   static __device__ __forceinline__ uint4 affine_lo(uint4 v, const float* sc, const float* sh, float lo) {
     float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = fmaxf(fmaf(x[i], sc[i], sh[i]), lo);
+    for (int i = 0; i < 4; ++i) x[i] = clamp_lo(fmaf(x[i], sc[i], sh[i]), lo);
     return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
   }
   static __device__ __forceinline__ float load(const void* p, size_t i) { return ((const float*)p)[i]; }

@@ -164,7 +164,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
               for (int j = 0; j < 4; ++j) {
                 float val = acc16[mb][nb][j];
                 if constexpr (HAS_BIAS) val += bias;
-                if constexpr (HAS_RELU) val = fmaxf(val, 0.f);
+                if constexpr (HAS_RELU) val = clamp_lo(val, 0.f);
                 if constexpr (HAS_STAT) { s1[nb] += val; s2[nb] += val * val; }
                 *(unsigned short*)(otile + ((wm * 2 * MT + mb) * TW + 4 * g16 + j) * OPITCH + cl * ES) = Tr<T>::bits16(val);
               }
@@ -184,7 +184,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             for (int i = 0; i < 16; ++i) {
               float val = acc[mt][nt][i];
               if constexpr (HAS_BIAS) val += bias;
-              if constexpr (HAS_RELU) val = fmaxf(val, 0.f);   // eval, BatchNorm folded: the activation is stored, not the raw conv output
+              if constexpr (HAS_RELU) val = clamp_lo(val, 0.f);   // eval, BatchNorm folded: the activation is stored, not the raw conv output
               if constexpr (HAS_STAT) { s1[nt] += val; s2[nt] += val * val; }
               int off, lb;
               if constexpr (GROUPED) {
@@ -341,7 +341,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
           const int ty = wm * 2 * MT + mb, tx = 4 * g16 + j;
           const int gy = y0 + ty, gx = x0 + tx;
           float val = acc16[mb][nb][j] + bias;
-          if (a.relu_out) val = fmaxf(val, 0.f);
+          if (a.relu_out) val = clamp_lo(val, 0.f);
           if (cok && gy < a.OH && gx < a.OW) {
             s1[nb] += val; s2[nb] += val * val;
             if (head) {
@@ -369,7 +369,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
         const int ty = wm * 2 * MT + mt * 2 + RowMap<GROUPED>::ty(rr), tx = RowMap<GROUPED>::tx(rr);
         const int gy = y0 + ty, gx = x0 + tx;
         float val = acc[mt][nt][i] + bias;
-        if (a.relu_out) val = fmaxf(val, 0.f);
+        if (a.relu_out) val = clamp_lo(val, 0.f);
         if (cok && gy < a.OH && gx < a.OW) {
           s1[nt] += val; s2[nt] += val * val;
           if (head) {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
     }
     if (a.relu) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) x[i] = fmaxf(x[i], 0.f);
+      for (int i = 0; i < VEC; ++i) x[i] = x[i] < 0.f ? 0.f : x[i];   // (torch's relu keeps a NaN; fmaxf would turn it into 0)
     }
     if (a.post) {
       float pp[VEC];

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, BRES ? 1 : 2) void gemm1x1_kernel(const G1Args
   float obias[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) obias[nt] = (a.bias != nullptr && n0 + nt * 32 + r < a.N) ? a.bias[n0 + nt * 32 + r] : 0.f;
-  const float ofloor = a.relu_out ? 0.f : -3.0e38f;
+  const float ofloor = a.relu_out ? 0.f : NO_FLOOR;
   const int bswz = (r >> 1) & 7;
   const int bbase = r * 128;
   const unsigned floor16 = a.relu ? 0u : 0x80008000u;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, BRES ? 1 : 2) void gemm1x1_kernel(const G1Args
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[nt][v] = fmaxf(acc[nt][v] + obias[nt], ofloor);
+        for (int v = 0; v < 16; ++v) acc[nt][v] = clamp_lo(acc[nt][v] + obias[nt], ofloor);
     }
     if (a.slab != nullptr) {
 #pragma unroll

@@ -179,6 +179,7 @@ class SegNet(nn.Module):
         self._plans = {}
         self.use_graph = use_graph
         self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
+        self._buffer_epoch = 0  # the same for bn_buffers (every train-mode forward)
         # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
         probe = _Plan(a, encoder_name, self.classes, 1, 32, 32, self.dtype_code)
         lib = L.lib()
@@ -379,10 +380,15 @@ class SegNet(nn.Module):
         plan.generation += 1   # this forward overwrites the plan's saved activations / BN statistics / Dice sums
         # in-place writes to the arena (torch optimizers, copy_, all-reduce) bump its version counter; the fused
         # optimizer calls params_changed() itself.  A changed version invalidates every plan's weight images.
-        ver = (self.arena._version, self.bn_buffers._version, self._param_epoch)   # (eval weight images fold the running statistics in)
-        if getattr(plan, 'seen_version', None) != ver:
+        ver = (self.arena._version, self._param_epoch)
+        # eval weight images fold the running statistics in: they are stale too once ANY plan's train-mode forward has updated
+        # bn_buffers through the raw pointer (torch's version counter does not see that write: _buffer_epoch does)
+        bver = (self.bn_buffers._version, self._buffer_epoch)
+        if getattr(plan, 'seen_version', None) != ver or (not train and getattr(plan, 'seen_buffers', None) != bver):
             L.check(L.lib().octseg_plan_params_changed(plan.handle))
             plan.seen_version = ver
+        if not train:
+            plan.seen_buffers = bver
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
         want_graph = bool(self.use_graph and not train)
@@ -413,6 +419,7 @@ class SegNet(nn.Module):
                                            L.stream_ptr()))
         if train:
             self.num_batches_tracked += 1
+            self._buffer_epoch += 1   # running_mean / running_var were rewritten behind torch's back
         return logits, plan
 
     def forward(self, x, normalize=False, mean=None, std=None):
@@ -460,7 +467,7 @@ class SegNet(nn.Module):
         all-reduce of each slice overlaps the rest of the backward; on return the gradients are the cross-rank sums."""
         logits, loss, stats, plan = self._forward_loss(image, target, normalize, mean, std)
         if exchange is not None:
-            exchange.backward(plan, logits, target, grad_scale)
+            exchange.backward(plan, logits, target, grad_scale, generation=plan.generation)
         else:
             self._backward(plan, logits, target, grad_scale, generation=plan.generation)
         self.arena.grad = self._grad_arena

@@ -28,19 +28,55 @@ def sensitivity(tp, fp, fn, tn, zero_division=1.0):
     return _div(tp, tp + fn, zero_division)
 
 
-def get_metrics_from_stats(stats, loss, eps=1e-7):
-    """stats: int64 tensor [B, C, 4] = tp, fp, fn, tn (one D2H copy, as the reference's .cpu())."""
-    s = stats.detach().cpu().numpy()
+def _metrics_from_numpy(s, loss, eps=1e-7):
     tp, fp, fn, tn = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
     iou = iou_score(tp, fp, fn, tn, eps)
     return {
-        'loss': loss.detach().cpu().numpy(),
+        'loss': loss,
         'iou': iou,
         'dice': 2 * iou / (iou + 1),
         'recall': sensitivity(tp, fp, fn, tn, eps),
         'precision': precision(tp, fp, fn, tn, eps),
         'f1': f1_score(tp, fp, fn, tn, eps),
     }
+
+
+def get_metrics_from_stats(stats, loss, eps=1e-7):
+    """stats: int64 tensor [B, C, 4] = tp, fp, fn, tn (one D2H copy, as the reference's .cpu())."""
+    return _metrics_from_numpy(stats.detach().cpu().numpy(), loss.detach().cpu().numpy(), eps)
+
+
+class DeferredMetrics:
+    """On-device accumulation of a split's step records: the reference's ``get_metrics`` copies tp / fp / fn / tn
+    and the loss to the host in EVERY step (``src/models/smp/utils.py:25-35`` -- a device sync per step).  Here the int64 counts
+    [B, C, 4] and the f32 loss of each step stay in HBM; ``flush()`` stacks them, crosses to the host once and builds the very
+    per-step dicts ``get_metrics_from_stats`` would have built (same integer counts, same float32 ratios), so the epoch rows of
+    ``save_metrics_on_epoch`` -- pairwise running mean included -- are bit-identical to the per-step path."""
+
+    def __init__(self):
+        self._stats, self._loss = [], []
+
+    def append(self, stats, loss):
+        self._stats.append(stats.detach())          # fresh tensors of the Dice launch: nothing overwrites them
+        self._loss.append(loss.detach().reshape(1))
+
+    def __len__(self):
+        return len(self._stats)
+
+    def flush(self, eps=1e-7):
+        import torch
+        if not self._stats:
+            return []
+        shapes = [tuple(s.shape) for s in self._stats]
+        flat = torch.cat([s.reshape(-1) for s in self._stats]).cpu().numpy()      # ONE copy of every count of the epoch
+        losses = torch.cat(self._loss).cpu().numpy()                                # ... and one of the losses
+        out, off = [], 0
+        for i, shp in enumerate(shapes):
+            n = int(np.prod(shp))
+            out.append(_metrics_from_numpy(flat[off:off + n].reshape(shp), losses[i].reshape(()), eps))
+            off += n
+        self._stats, self._loss = [], []
+        return out
 
 
 def aggregate_epoch(metrics_epoch):

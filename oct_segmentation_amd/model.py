@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .engine import SegNet, get_preprocessing_params
-from .metrics import get_metrics_from_stats
+from .metrics import DeferredMetrics, get_metrics_from_stats
 
 # reference src/data/utils.py:16-45
 CLASS_IDS = {'Lumen': 1, 'Fibrous cap': 2, 'Lipid core': 3, 'Vasa vasorum': 4}
@@ -70,7 +70,7 @@ class OCTSegmentationModel(nn.Module):
     def __init__(self, arch, encoder_name, model_name, in_channels, classes, lr=0.0001, data_dir=None,
                  weight_decay=0.0001, optimizer_name='Adam', input_size=512, img_save_interval=1,
                  save_wandb_media=False, device='cuda', compute_dtype=torch.bfloat16, fused_optimizer=True, encoder_weights=None,
-                 **kwargs):
+                 defer_metrics=False, **kwargs):
         super().__init__()
         # **kwargs go to the network factory as in the reference (model.py:38-44 -> smp.create_model); SegNet rejects what it
         # does not implement.  encoder_weights: see SegNet (the reference's smp default 'imagenet' needs a download).
@@ -86,6 +86,10 @@ class OCTSegmentationModel(nn.Module):
         self._mean, self._std = list(params['mean']), list(params['std'])
         self.training_step_outputs = []
         self.validation_step_outputs = []
+        # defer_metrics=False keeps the reference's per-step dict (one D2H copy of the counts per step, utils.py:25-35);
+        # True keeps the counts and the loss on the GPU until flush_metrics() -- one copy per epoch, same rows
+        self.defer_metrics = bool(defer_metrics)
+        self._deferred = {'train': DeferredMetrics(), 'test': DeferredMetrics()}
         self.validation_best_metrics = {}
         self.loss_fn = DiceLoss()
         self.model_name = model_name
@@ -105,16 +109,34 @@ class OCTSegmentationModel(nn.Module):
         return loss, logits, stats
 
     # ---- model.py:73-95.  The thresholded mask and tp/fp/fn/tn come out of the Dice kernel.
+    def record_step(self, split, stats, loss):
+        """What get_metrics + the append in training_step / validation_step do (model.py:82-92, 116-126)."""
+        if self.defer_metrics:
+            self._deferred[split].append(stats, loss)
+        else:
+            (self.training_step_outputs if split == 'train' else self.validation_step_outputs).append(get_metrics_from_stats(stats, loss))
+
+    def flush_metrics(self, split):
+        """The split's per-step metric dicts of the epoch so far (deferred mode: the one host copy happens here)."""
+        outputs = self.training_step_outputs if split == 'train' else self.validation_step_outputs
+        if self.defer_metrics:
+            outputs.extend(self._deferred[split].flush())
+        return outputs
+
     def training_step(self, batch, batch_idx=0):
         loss, logits, stats = self._step(batch)
-        self.training_step_outputs.append(get_metrics_from_stats(stats, loss))
+        self.record_step('train', stats, loss)
         return {'loss': loss}
 
     # ---- model.py:108-132
     def validation_step(self, batch, batch_idx=0):
         with torch.no_grad():
             loss, logits, stats = self._step(batch)
-        self.validation_step_outputs.append(get_metrics_from_stats(stats, loss))
+        self.record_step('test', stats, loss)
+        if self.defer_metrics:   # no host copy: the batch F1 as a device scalar (2tp / (2tp + fp + fn), 0/0 -> 1e-7 as utils.py:17)
+            tp, fp, fn = stats[..., 0].float(), stats[..., 1].float(), stats[..., 2].float()
+            f1 = torch.nan_to_num(2 * tp / (2 * tp + fp + fn), nan=1e-7)
+            return {'val/loss': loss, 'val/f1': f1.mean()}
         return {'val/loss': loss, 'val/f1': float(np.mean(self.validation_step_outputs[-1]['f1']).mean())}
 
     # ---- model.py:150-181

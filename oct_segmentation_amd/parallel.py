@@ -43,30 +43,49 @@ class GradientExchange:
         self.comm = torch.cuda.Stream(device=net.device)
         self.fired = []          # (slice, begin, end) in completion order of the last step (tests / diagnostics)
         self._works = []
+        self._error = None
         self._cb = L.SLICE_CB(self._on_slice)   # keep the ctypes thunk alive
 
     def _on_slice(self, _user, k, begin, end):
-        self.fired.append((int(k), int(begin), int(end)))
-        g = self.net._grad_arena[begin:end]
-        with torch.cuda.stream(self.comm):
-            w = _all_reduce_sum(g)
-        if w is not None:
-            self._works.append(w)
+        # called from C (ctypes swallows Python exceptions raised in a callback): keep the first one for backward() to re-raise
+        try:
+            self.fired.append((int(k), int(begin), int(end)))
+            if self._error is not None:
+                return            # a collective already failed: issue no more, peers are released by the abort below
+            g = self.net._grad_arena[begin:end]
+            with torch.cuda.stream(self.comm):
+                w = _all_reduce_sum(g)
+            if w is not None:
+                self._works.append(w)
+        except BaseException as e:   # noqa: BLE001 -- must not propagate into the C caller
+            self._error = e
 
-    def backward(self, plan, logits, target, grad_scale):
+    def backward(self, plan, logits, target, grad_scale, generation=None):
         net = self.net
-        self.fired, self._works = [], []
+        if generation is not None and generation != plan.generation:
+            raise RuntimeError(f'backward of a stale step: another forward of shape {plan.shape} ran on this network since the step '
+                               f'whose gradients are being exchanged')
+        self.fired, self._works, self._error = [], [], None
         cur = torch.cuda.current_stream(net.device)
         L.check(L.lib().octseg_net_backward_sliced(plan.handle, L.ptr(net.arena.data), L.ptr(net._grad_arena),
                                                    L.ptr(plan.ws(logits.device)), L.ptr(logits), L.ptr(target.contiguous()),
                                                    float(grad_scale), L.stream_ptr(), self.nslices,
                                                    C.c_void_p(self.comm.cuda_stream), self._cb, None))
+        if self._error is not None:
+            # some slices were reduced, some were not: this rank cannot finish the step and its peers may be blocked inside a
+            # collective it never joined -- tear the group down (nccl: abort) so that they fail too instead of hanging
+            err = self._error
+            try:
+                dist.destroy_process_group()
+            except Exception:   # noqa: BLE001
+                pass
+            raise RuntimeError(f'gradient exchange failed in slice callback: {err!r}') from err
         for w in self._works:
             w.wait()              # nccl: the current stream waits for the collective (no host block)
         cur.wait_stream(self.comm)
         covered = sorted((b, e) for _, b, e in self.fired)
-        assert covered[0][0] == 0 and covered[-1][1] == net.param_numel and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), \
-            'the slices reported by the engine do not tile the gradient arena'
+        if not covered or covered[0][0] != 0 or covered[-1][1] != net.param_numel or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+            raise RuntimeError(f'the slices reported by the engine do not tile the gradient arena: {covered}')
         return net._grad_arena
 
 

@@ -66,15 +66,30 @@ def cv2_linear_coeffs(src, dst, horizontal=True):
     return s0, s1, a0, a1
 
 
+def _is_exact_half(src, dst):
+    """OpenCV's ``is_area_fast && iscale == 2`` per axis: scale = 1. / ((double)dst / src), iscale = saturate_cast<int>(scale) (= cvRound),
+    |scale - iscale| < DBL_EPSILON."""
+    scale = 1.0 / (dst / float(src))
+    return int(np.rint(scale)) == 2 and abs(scale - 2.0) < np.finfo(np.float64).eps
+
+
 def cv2_resize_linear_u8(img, dst_w, dst_h):
     """``cv2.resize(img_u8, (dst_w, dst_h))`` (default INTER_LINEAR) restated: horizontal pass in int32 with 11-bit
-    coefficients, vertical pass ``(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`` (VResizeLinear<uchar>)."""
+    coefficients, vertical pass ``(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`` (VResizeLinear<uchar>); an exact 2x
+    decimation in both axes (e.g. 1024 -> 512) takes OpenCV's INTER_AREA fast path instead, as cv::resize does."""
     img = np.asarray(img)
     assert img.dtype == np.uint8
     squeeze = img.ndim == 2
     if squeeze:
         img = img[:, :, None]
     H, W = img.shape[:2]
+    if _is_exact_half(W, dst_w) and _is_exact_half(H, dst_h):
+        # cv::resize switches INTER_LINEAR to INTER_AREA for an exact 2x decimation (resize.cpp: `interpolation == INTER_LINEAR &&
+        # is_area_fast && iscale_x == 2 && iscale_y == 2`); the 8-bit fast path (ResizeAreaFastVec, cn = 1 / 3 / 4) averages each
+        # 2x2 block as (a + b + c + d + 2) >> 2
+        s = img.astype(np.int64)
+        out = ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        return out[:, :, 0] if squeeze else out
     x0, x1, ax0, ax1 = cv2_linear_coeffs(W, dst_w)
     y0, y1, ay0, ay1 = cv2_linear_coeffs(H, dst_h, horizontal=False)
     src = img.astype(np.int64)

@@ -4,6 +4,7 @@ steps it on batches from any iterable of ``(img [B,3,S,S] f32 0..255 BGR, mask [
 reference's ``config.json`` + ``weights.ckpt`` pair.  Data parallel when launched under torchrun."""
 import json
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -23,7 +24,25 @@ def write_model_config(cfg, model_dir):
                    'batch_size': cfg['batch_size'], 'optimizer': cfg['optimizer'], 'lr': cfg['lr']}, f, indent=2)
 
 
+def write_epoch_rows(model_dir, classes, epoch, train_outputs, val_outputs, best_metrics):
+    """metrics.csv rows of one epoch in the reference's order: Lightning runs the validation loop inside the training epoch, so
+    ``on_validation_epoch_end`` (model.py:134-148: the 'test' rows + best metrics) writes BEFORE ``on_train_epoch_end``
+    (model.py:97-106: the 'train' rows) -- eval/training/Lumen/fold_1/metrics.csv:2-3.  Returns the updated best metrics."""
+    if val_outputs:
+        _, best_metrics = save_metrics_on_epoch(val_outputs, 'test', model_dir, classes, epoch, best_metrics)
+    save_metrics_on_epoch(train_outputs, 'train', model_dir, classes, epoch)
+    return best_metrics
+
+
+_warned_random_init = False
+
+
 def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, augment_seed=None):
+    """``cfg`` keys beyond train.yaml's: ``compute_dtype`` ('bf16' | 'fp32'), ``allreduce_slices``, ``encoder_weights`` (passed to
+    the network factory: None = random init, a path / 'imagenet' = torchvision weights, see SegNet.load_encoder_weights) and
+    ``defer_metrics`` (True: tp/fp/fn/tn and the loss of every step stay on the GPU and cross to the host ONCE per epoch instead
+    of once per step -- the per-step ``.cpu()`` of utils.py:25-35 is a device sync; the epoch rows are identical)."""
+    global _warned_random_init
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
         import torch.distributed as dist
@@ -33,9 +52,16 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
         if dist.get_world_size() != world:
             raise RuntimeError(f'WORLD_SIZE={world} but the process group has {dist.get_world_size()} ranks')
     dt = torch.float32 if str(cfg.get('compute_dtype', 'bf16')) in ('fp32', 'float32') else torch.bfloat16
+    enc_w = cfg.get('encoder_weights')
+    if enc_w is None and not os.environ.get('OCTSEG_IMAGENET_DIR') and not _warned_random_init:
+        # the reference's smp.create_model default is encoder_weights='imagenet' (model.py:38-44): say that this run differs
+        warnings.warn("fit(): encoder_weights is None and OCTSEG_IMAGENET_DIR is unset -- the encoder starts from random init, "
+                      "where the reference downloads ImageNet weights; pass cfg['encoder_weights']", stacklevel=2)
+        _warned_random_init = True
     model = OCTSegmentationModel(cfg['architecture'], cfg['encoder'], f"{cfg['architecture']}_{cfg['encoder']}", 3,
                                  cfg['classes'], lr=cfg['lr'], weight_decay=cfg['weight_decay'],
-                                 optimizer_name=cfg['optimizer'], input_size=cfg['input_size'], device=device, compute_dtype=dt)
+                                 optimizer_name=cfg['optimizer'], input_size=cfg['input_size'], device=device, compute_dtype=dt,
+                                 encoder_weights=enc_w, defer_metrics=bool(cfg.get('defer_metrics', False)))
     net = model.model
     exchange = None
     if world > 1:
@@ -63,27 +89,29 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
             loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
                                                      grad_scale=1.0 / world, exchange=exchange)
             opt.step()
-            from .metrics import get_metrics_from_stats
-            model.training_step_outputs.append(get_metrics_from_stats(stats, loss))
-        row = {'epoch': epoch, 'train': aggregate_epoch(model.training_step_outputs)}
-        if model_dir is not None and rank0:   # model.py:97-106: metrics.csv rows of the train split
-            save_metrics_on_epoch(model.training_step_outputs, 'train', model_dir, cfg['classes'], epoch)
-        if val_batches is not None:
+            model.record_step('train', stats, loss)
+        row = {'epoch': epoch}
+        val_outputs = None
+        if val_batches is not None:   # Lightning runs the validation loop before on_train_epoch_end
             model.eval()
             model.validation_step_outputs.clear()
-            vsum, vcount = 0.0, 0
+            vloss, vcount = [], []
             for batch in val_batches:
                 out = model.validation_step(batch)
-                vsum += float(out['val/loss']) * batch[0].shape[0]   # self.log('val/loss', on_epoch=True): batch-size-weighted mean
-                vcount += batch[0].shape[0]
-            row['val/loss'] = vsum / max(vcount, 1)
+                vloss.append(out['val/loss'].detach().reshape(1))   # self.log('val/loss', on_epoch=True): batch-size-weighted mean
+                vcount.append(batch[0].shape[0])
+            w = torch.tensor(vcount, dtype=torch.float64)
+            row['val/loss'] = float((torch.cat(vloss).double().cpu() * w).sum() / max(float(w.sum()), 1.0))   # one D2H per epoch
             if model_dir is not None and rank0 and (best_val is None or row['val/loss'] < best_val):
                 best_val = row['val/loss']      # only the best-validation-loss epoch is kept, as predict.py then loads it
                 model.save_checkpoint(os.path.join(model_dir, 'weights.ckpt'), epoch=epoch)
-            row['test'] = aggregate_epoch(model.validation_step_outputs)   # the reference calls the split 'test'
-            if model_dir is not None and rank0:   # model.py:134-148: test rows + best metrics
-                _, model.validation_best_metrics = save_metrics_on_epoch(model.validation_step_outputs, 'test', model_dir, cfg['classes'],
-                                                                         epoch, model.validation_best_metrics)
+            val_outputs = model.flush_metrics('test')
+            row['test'] = aggregate_epoch(val_outputs)   # the reference calls the split 'test'
+        train_outputs = model.flush_metrics('train')
+        row['train'] = aggregate_epoch(train_outputs)
+        if model_dir is not None and rank0:
+            model.validation_best_metrics = write_epoch_rows(model_dir, cfg['classes'], epoch, train_outputs, val_outputs,
+                                                             model.validation_best_metrics)
         history.append(row)
     if model_dir is not None and rank0 and val_batches is None:   # nothing to monitor: keep the last epoch
         model.save_checkpoint(os.path.join(model_dir, 'weights.ckpt'), epoch=len(history))

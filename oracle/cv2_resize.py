@@ -67,6 +67,19 @@ def resize_linear_u8(src, dsize):
         return resize_linear_u8(src[:, :, None], dsize)[:, :, 0]
     dw, dh = int(dsize[0]), int(dsize[1])
     sh, sw, cn = src.shape
+    # cv::resize: scale_x = 1. / inv_scale_x; iscale_x = saturate_cast<int>(scale_x); is_area_fast = both |scale - iscale| < DBL_EPSILON;
+    # `if (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA;` and the 8-bit
+    # resizeAreaFast_ with ResizeAreaFastVec (fast_mode: scale 2x2, cn in {1, 3, 4}): D = (S[i] + S[i + cn] + nextS[i] + nextS[i + cn] + 2) >> 2
+    scale_x, scale_y = 1.0 / (dw / float(sw)), 1.0 / (dh / float(sh))
+    eps = 2.220446049250313e-16
+    if int(round(scale_x)) == 2 and int(round(scale_y)) == 2 and abs(scale_x - 2) < eps and abs(scale_y - 2) < eps and cn in (1, 3, 4):
+        out = np.empty((dh, dw, cn), dtype=np.uint8)
+        for y in range(dh):
+            for x in range(dw):
+                for c in range(cn):
+                    out[y, x, c] = (int(src[2 * y, 2 * x, c]) + int(src[2 * y, 2 * x + 1, c]) + int(src[2 * y + 1, 2 * x, c]) +
+                                    int(src[2 * y + 1, 2 * x + 1, c]) + 2) >> 2
+        return out
     xofs, xa = _linear_tabs(sw, dw, True)
     yofs, ya = _linear_tabs(sh, dh, False)
     out = np.empty((dh, dw, cn), dtype=np.uint8)

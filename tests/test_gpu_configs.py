@@ -8,7 +8,7 @@
 
 plus the bf16 engine -- the benchmarked dtype -- against the fp32 oracle at >= 256x256 on the bottleneck encoder
 (U-Net++/resnet50, LinkNet/resnet50): Dice loss <= 1e-3 (north_star), logits <= 3 % of their scale, global gradient
-cosine >= 0.99 (kink-free BN biases: ReLU masks are then stable under bf16 rounding).
+cosine >= 0.9995 (kink-free BN biases: ReLU masks are then stable under bf16 rounding).
 
 Full-size cases cannot run the CPU oracle in reasonable time (45 TFLOP per step), so they check size-independent
 properties: finite outputs, a deterministic forward, eval-mode batch-permutation equivariance, confusion counts equal
@@ -181,7 +181,7 @@ def test_bf16_engine_vs_fp32_oracle_bottleneck_256(cuda, cfg):
     print(f'{cfg}: bf16 logits {err:.2e}/{scale:.1f} ({err / max(scale, 1):.2%}; torch autocast {err_ac:.2e}), Dice loss {loss.item():.6f} vs '
           f'{loss_ref.item():.6f}, hard Dice {d_eng:.5f} vs {d_ref:.5f} (autocast {d_ac:.5f}), grad cosine {cos:.5f}')
     assert abs(loss.item() - loss_ref.item()) <= 1e-3            # north_star: Dice within 1e-3 of the reference
-    assert cos >= 0.99
+    assert cos >= 0.9995                                         # (measured 0.99994 .. 0.999999 on these nets)
     # element-wise logits and the thresholded masks of a randomly initialised net (hard Dice ~0.3: most pixels sit near the
     # threshold): 3 % of the logit scale / 1e-3, or what torch's own bf16 autocast of the same net deviates by
     assert err <= max(3e-2 * max(1.0, scale), 1.5 * err_ac)

@@ -89,6 +89,30 @@ def test_plan_cache_and_mode_switch(cuda):
         net(torch.zeros(1, 1, 64, 64, device=cuda))
 
 
+def test_eval_on_one_plan_sees_running_stats_updated_through_another(cuda):
+    """Eval weight images fold the running statistics in and are cached per (B, H, W) plan.  A train-mode forward on plan B rewrites
+    bn_buffers through the raw pointer (no torch version bump, no optimizer step): an eval forward on plan A afterwards must fold the
+    NEW statistics (BN recalibration / training_step without opt.step followed by predict)."""
+    ref, net = _pair('unet', 'resnet18', 1, cuda)
+    imgA, _ = make_batch(1, 1, 64, seed=5)
+    imgB, _ = make_batch(2, 1, 96, seed=6)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        z0 = ref(imgA)
+    y0 = net(imgA.to(cuda)).cpu()                     # plan A packed for eval with the initial statistics
+    assert (y0 - z0).abs().max().item() <= 1e-4 * max(1.0, z0.abs().max().item())
+    ref.train(); net.train()
+    with torch.no_grad():
+        ref(imgB)                                     # updates the oracle's running statistics
+    net(imgB.to(cuda))                                # plan B, train mode: bn_buffers rewritten in place
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        z1 = ref(imgA)
+    y1 = net(imgA.to(cuda)).cpu()                     # plan A again: must not reuse the stale folded images
+    assert (z1 - z0).abs().max().item() > 1e-3        # (the statistics really moved the eval output)
+    assert (y1 - z1).abs().max().item() <= 1e-4 * max(1.0, z1.abs().max().item())
+
+
 def test_full_size_properties_bf16_704(cuda):
     """BASELINE size (704x704, bf16), U-Net/resnet18 to keep the CPU side out of it: properties that do not
     need the oracle -- finiteness, determinism of the forward, batch-permutation equivariance in eval mode,
@@ -134,10 +158,38 @@ def test_fit_loop_writes_reference_style_model_dir(cuda, tmp_path):
     import csv
     rows = list(csv.DictReader(open(os.path.join(tmp_path, 'metrics.csv'))))   # train + test rows, per class + Mean, per epoch
     assert len(rows) == 2 * 2 * 2 and {r['Split'] for r in rows} == {'train', 'test'} and rows[1]['Class'] == 'Mean'
+    # the reference's order: validation ('test') rows of an epoch precede its training rows (model.py:134-148 before :97-106;
+    # eval/training/Lumen/fold_1/metrics.csv:2-3)
+    assert [(r['Epoch'], r['Split']) for r in rows] == [('1', 'test')] * 2 + [('1', 'train')] * 2 + [('2', 'test')] * 2 + [('2', 'train')] * 2
     m2, cfg2 = load_model(str(tmp_path), 'cuda', torch.float32)
     assert torch.equal(m2.model.arena.data, model.model.arena.data)
     out = m2.predict(np.zeros((1, 64, 64, 3), np.float32), 'cuda')
     assert out.shape == (1, 64, 64, 1)
+
+
+def test_fit_with_deferred_metrics_writes_the_same_csv(cuda, tmp_path):
+    """cfg['defer_metrics']: counts and losses stay on the GPU, one host copy per epoch (the reference syncs every step,
+    utils.py:25-35).  Same steps (deterministic reductions), so metrics.csv must be byte-identical to the per-step path."""
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.config import load_config
+    from oct_segmentation_amd.train import fit
+    cfg = load_config('train', ['architecture=linknet', 'encoder=resnet18', 'epochs=2', 'input_size=64', 'batch_size=2', 'lr=0.001',
+                                'compute_dtype=fp32', 'use_augmentation=false'])
+    cfg['classes'] = ['Lipid core', 'Fibrous cap']
+    batches = [tuple(t.to(cuda) for t in make_batch(2, 2, 64, seed=s)) for s in (4, 5, 6)]
+    L.check(L.lib().octseg_set_deterministic(1))
+    try:
+        out = []
+        for defer in (False, True):
+            torch.manual_seed(7)
+            d = tmp_path / ('defer' if defer else 'step')
+            model, hist = fit(dict(cfg, defer_metrics=defer), batches, val_batches=batches[1:], device=cuda, model_dir=str(d))
+            assert model.defer_metrics is defer
+            out.append(((d / 'metrics.csv').read_bytes(), hist))
+    finally:
+        L.check(L.lib().octseg_set_deterministic(0))
+    assert out[0][0] == out[1][0] and len(out[0][0]) > 200
+    assert out[0][1][1]['val/loss'] == out[1][1][1]['val/loss']
 
 
 def test_fit_loop_with_gpu_augmentation(cuda, tmp_path):

@@ -181,9 +181,8 @@ if not any(c[2] == 'resnet50' for c in _BF16):   # the sequence must exercise th
 
 @pytest.mark.parametrize('case', _BF16, ids=[f'k{c[0]}-{c[1]}-{c[2]}-B{c[3]}-C{c[4]}-{c[5]}x{c[6]}' for c in _BF16])
 def test_fuzz_train_step_bf16(cuda, case):
-    """bf16 engine against the fp32 oracle: logits within 3 % of their scale (or 1.5 x the error of torch's CPU bf16 autocast of the oracle, whichever is larger), Dice loss within 5e-3 (1e-3 is the bar at
-    the benchmark's size, test_gpu_configs.py; these 2-4 frame batches of <= 224 px have few pixels per class), global gradient
-    cosine >= 0.99 (kink-free nets)."""
+    """bf16 engine against the fp32 oracle: logits within 3 % of their scale (or 1.5 x the error of torch's CPU bf16 autocast of the oracle, whichever is larger), Dice loss within 1e-3 (2.5e-3 for batches of
+    fewer than 40 k pixels: few pixels per class), global gradient cosine >= 0.999 (kink-free nets)."""
     from oracle import DiceLoss
     from oct_segmentation_amd.engine import SegNet
     k, arch, enc, B, classes, H, W = case
@@ -206,5 +205,7 @@ def test_fuzz_train_step_bf16(cuda, case):
         err_ac = (ref(img).float() - z.detach()).abs().max().item()
     print(f'k={k} bf16 {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.1f} (autocast {err_ac:.1e}) loss {abs(loss.item() - loss_ref.item()):.1e} cos {cos:.6f}')
     assert err <= max(3e-2 * max(1.0, scale), 1.5 * err_ac)
-    assert abs(loss.item() - loss_ref.item()) <= 5e-3
-    assert cos > 0.99
+    # bounds sit at what is measured, not 10-100x above it (two 40-case runs, profiles/r2_fuzz_bf16_seed777.txt: cosine 0.9993 .. 0.999999,
+    # Dice loss error <= 1.3e-3, <= 1e-3 from 40 k pixels per batch upwards): a regression that halves bf16 gradient quality turns red
+    assert abs(loss.item() - loss_ref.item()) <= (1e-3 if B * H * W >= 40000 else 2.5e-3)
+    assert cos > 0.999

@@ -162,3 +162,71 @@ def test_two_ranks_one_gpu_real_process_group(cuda):
         assert res[r][7], 'gradients differ between the ranks after the exchange'
         assert res[r][8], 'parameters diverged between the ranks after the optimizer step'
     _ = build
+
+
+_RCCL_WORLD1 = r'''
+import json, os, sys
+ROOT = sys.argv[1]; port = int(sys.argv[2])
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device('cuda:0')
+dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0, device_id=dev)
+out = {}
+try:
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd import parallel as P
+    from oct_segmentation_amd.engine import SegNet
+    from oct_segmentation_amd.model import FusedOptimizer
+    from synth import make_batch
+    L.check(L.lib().octseg_set_deterministic(1))      # no racing atomics: the two backward runs below are comparable bit for bit
+    net = SegNet('unet', 'resnet18', classes=2, device=dev, compute_dtype=torch.float32, seed=5).train()
+    P.broadcast_parameters(net)                       # ncclBroadcast of the arena and of the BN buffers
+    P.broadcast_buffers(net)
+    img, mask = (t.to(dev) for t in make_batch(2, 2, 64, seed=8))
+    loss0, _, _ = net.train_step_raw(img, mask, grad_scale=1.0)
+    torch.cuda.synchronize()
+    g0 = net._grad_arena.clone()
+    net.bn_buffers.zero_()
+    ex = P.GradientExchange(net, nslices=3)
+    loss1, _, _ = net.train_step_raw(img, mask, grad_scale=1.0, exchange=ex)     # async_op all-reduce per slice on the comm stream
+    torch.cuda.synchronize()
+    out['backend'] = dist.get_backend()
+    out['same_loss'] = bool(loss0.item() == loss1.item())
+    out['same_grads'] = bool(torch.equal(g0, net._grad_arena))
+    out['fired'] = [list(f) for f in ex.fired]
+    out['works'] = len(ex._works)
+    out['numel'] = int(net.param_numel)
+    g2 = P.allreduce_gradients(net, world=1).clone()                              # the unsliced collective
+    torch.cuda.synchronize()
+    out['allreduce_identity'] = bool(torch.equal(g2, g0))
+    before = net.arena.data.clone()
+    FusedOptimizer(net, 'Adam', 1e-3, 0.0).step()
+    torch.cuda.synchronize()
+    out['stepped'] = bool(not torch.equal(before, net.arena.data) and torch.isfinite(net.arena.data).all())
+finally:
+    dist.destroy_process_group()
+print('RESULT ' + json.dumps(out), flush=True)
+'''
+
+
+@pytest.mark.timeout(600)
+def test_rccl_branch_world_size_one(cuda):
+    """The RCCL ("nccl") branch of the exchange, executed for real on the one GPU there is: init_process_group('nccl', world_size=1,
+    device_id=...), GradientExchange(nslices=3) forced on -- async_op all-reduces issued from the slice callbacks on the communication
+    stream, Work.wait() and the stream joins -- must leave the gradient arena bit-identical to the exchange-free step (an all-reduce
+    over one rank is the identity), with the slices fired decoder / head range first (reference: torch DDP's bucket order under
+    Lightning, src/models/smp/train.py:122-133).  Runs in a child process so that the process group never leaks into other tests."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_WORLD1, ROOT, str(_free_port())], capture_output=True, text=True, timeout=540, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][-1]
+    out = json.loads(line[len('RESULT '):])
+    assert out['backend'] == 'nccl' and out['works'] == 3
+    assert out['same_loss'] and out['same_grads'] and out['allreduce_identity'] and out['stepped'], out
+    fired = out['fired']
+    assert sorted(k for k, _, _ in fired) == [0, 1, 2] and [k for k, _, _ in fired] == [2, 1, 0], fired
+    assert fired[-1][1] == 0 and fired[0][2] == out['numel']

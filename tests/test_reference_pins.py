@@ -108,3 +108,52 @@ def test_published_training_log_identity_dice_equals_f1():
     tp, fp, fn, tn = get_stats(pred.long(), mask.long())
     p = get_metrics_from_stats(torch.stack([tp, fp, fn, tn], dim=-1), torch.tensor(0.1))
     assert np.allclose(p['dice'], p['f1'], rtol=3e-7, atol=0)
+
+
+def test_epoch_rows_are_written_in_the_reference_order(fx, tmp_path):
+    """The epoch bookkeeping of the train loop (train.write_epoch_rows, what fit() calls) against the reference's file: Lightning runs
+    on_validation_epoch_end (model.py:134-148, 'test' rows + best metrics) BEFORE on_train_epoch_end (model.py:97-106, 'train' rows);
+    a whole csv must equal the reference's byte for byte, row order included."""
+    from oct_segmentation_amd.train import write_epoch_rows
+    for case in fx['epoch_cases']:
+        d = tmp_path / ('order_' + case['name'])
+        best = {}
+        for ep in case['epochs']:
+            best = write_epoch_rows(str(d), case['classes'], ep['epoch'], _batches(ep), _batches(ep), best)
+        with open(d / 'metrics.csv', newline='') as f:
+            rows = list(csv.DictReader(f))
+        assert rows == case['csv_rows'], case['name']
+        per = len(case['classes']) + 1
+        assert [r['Split'] for r in rows[:2 * per]] == ['test'] * per + ['train'] * per
+
+
+def test_deferred_metrics_equal_the_per_step_dicts(fx, tmp_path):
+    """One host copy per epoch (metrics.DeferredMetrics) must give the dicts the per-step path gives: same counts, same float32
+    ratios, hence the same csv bytes (reference: the per-step .cpu() of utils.py:25-35 is what is being removed)."""
+    from oct_segmentation_amd.metrics import DeferredMetrics, get_metrics_from_stats, save_metrics_on_epoch
+    g = torch.Generator().manual_seed(11)
+    steps = []
+    for i in range(5):
+        B = 1 + i % 3
+        tp = torch.randint(0, 50, (B, 2), generator=g)
+        fp = torch.randint(0, 50, (B, 2), generator=g)
+        fn = torch.randint(0, 50, (B, 2), generator=g)
+        if i == 2:
+            tp[0, 1] = fp[0, 1] = fn[0, 1] = 0          # an empty class: zero_division path
+        tn = 4096 - tp - fp - fn
+        steps.append((torch.stack([tp, fp, fn, tn], dim=-1), torch.rand((), generator=g)))
+    acc = DeferredMetrics()
+    eager = []
+    for s, l in steps:
+        acc.append(s, l)
+        eager.append(get_metrics_from_stats(s, l))
+    assert len(acc) == 5
+    late = acc.flush()
+    assert len(acc) == 0 and len(late) == len(eager)
+    for a, b in zip(late, eager):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]) and np.asarray(a[k]).dtype == np.asarray(b[k]).dtype and np.shape(a[k]) == np.shape(b[k]), k
+    save_metrics_on_epoch(late, 'test', str(tmp_path / 'a'), ['x', 'y'], 1, {})
+    save_metrics_on_epoch(eager, 'test', str(tmp_path / 'b'), ['x', 'y'], 1, {})
+    assert (tmp_path / 'a' / 'metrics.csv').read_bytes() == (tmp_path / 'b' / 'metrics.csv').read_bytes()
