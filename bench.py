@@ -183,6 +183,8 @@ def cpu_baseline(arch, enc, classes, size, batch=2, timed=3):
                       f'time budget): fp32 {[round(t, 2) for t in t32]} s, bf16 autocast {[round(t, 2) for t in t16]} s'}
 
 
+_RESULT_OUT = sys.stdout
+
 ENSEMBLE = (('LM', 'unetplusplus', 'resnet101', ['Lumen']), ('FC_LC', 'linknet', 'resnet50', ['Lipid core', 'Fibrous cap']),
             ('VV', 'unet', 'resnet50', ['Vasa vasorum']))
 
@@ -265,10 +267,16 @@ def bench_ensemble(args):
                         'avg_launch_ms': round(prof[0] / max(prof[2], 1.0), 4), 'algorithmic_gflop_per_frame': round(2 * macs / 1e9, 1),
                         'note': 'HIP-event brackets of every conv launch in an untimed eager one-stream pass of the same step'}}
     print(f'[bench] ensemble: {out["value"]} frames/s, {out["ms_per_step"]} ms/step; conv kernels alone {ach:.1f} TFLOP/s', file=sys.stderr, flush=True)
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=_RESULT_OUT, flush=True)
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to file descriptor 1 (RCCL writes its version block there when
+    # a communicator is created) are sent to stderr for the life of the process; the result goes to the saved descriptor
+    global _RESULT_OUT
+    sys.stdout.flush()
+    _RESULT_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -485,7 +493,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             note('CPU baseline (oracle, 2 frames per step, fp32 + bf16 autocast) ...')
             out['cpu_baseline'] = cpu_baseline(arch, enc, classes, S)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_RESULT_OUT, flush=True)
     if dp:
         torch.distributed.destroy_process_group()
 

@@ -67,6 +67,12 @@ struct ConvArgs {
   int src_uniform;        // set by launch_conv: every source starts on a K-chunk boundary (the per-chunk source choice is then scalar)
   int tile_order;         // set by launch_conv: 0 N-major, 1 M-major placement of the tiles on the XCDs (speed only)
   unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only: per-phase cycle sums, else nullptr
+  // fp32 master weights of the layer ([wtaps][wO][wI], the parameter arena's layout) for kernels that build their operands from them
+  // instead of the packed image (thin.hip); wtrans = 1: data gradient (output rows run over wI, the contraction over wO);
+  // wscale: eval forwards, the BatchNorm scale folded into output row `co` (nullptr: none).  Wmaster == nullptr: not available.
+  const float* Wmaster;
+  int wO, wI, wtrans;
+  const float* wscale;
 };
 
 struct WgradArgs {

@@ -1377,6 +1377,7 @@ static bool flatten_1x1(ConvArgs& a) {
 }
 
 int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
+  if (thin_conv_eligible(a0, dtype)) return thin_conv_rows(a0);
   if (gemm1x1_eligible(a0, dtype)) return gemm1x1_rows(a0);
   if (conv3x3p_eligible(a0, dtype)) return conv3x3p_rows(a0);
   ConvArgs a = a0;
@@ -1386,6 +1387,7 @@ int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
 
 hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
   if (a0.ntaps <= 0) return hipSuccess;
+  if (thin_conv_eligible(a0, dtype)) return launch_thin_conv(dtype, a0, st);
   if (gemm1x1_eligible(a0, dtype)) return launch_gemm1x1(dtype, a0, st);
   if (conv3x3p_eligible(a0, dtype)) return launch_conv3x3p(dtype, a0, st);
   ConvArgs a = a0;

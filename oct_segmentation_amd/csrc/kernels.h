@@ -33,6 +33,15 @@ bool conv3x3p_eligible(const ConvArgs& a, int dtype);
 int conv3x3p_rows(const ConvArgs& a);
 hipError_t launch_conv3x3p(int dtype, const ConvArgs& a, hipStream_t st);
 
+// thin.hip: 3x3 stride-1 layers with 16 / 32 input and <= 32 output channels on large maps (the last decoder block and the head) as
+// HBM-bound persistent kernels: forward / data gradient (weights as the MFMA A operand, built from the fp32 master weights; BN-stat
+// slab: one row per workgroup = thin_conv_rows) and weight gradient.  launch_conv / launch_wgrad route eligible launches there.
+bool thin_conv_eligible(const ConvArgs& a, int dtype);
+int thin_conv_rows(const ConvArgs& a);
+hipError_t launch_thin_conv(int dtype, const ConvArgs& a, hipStream_t st);
+bool thin_wgrad_eligible(const WgradArgs& a, int dtype);
+hipError_t launch_thin_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 

@@ -536,6 +536,7 @@ static int build_plan(octseg_plan* P) {
         DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; dd.C = L.Cout; dd.cn = L.Cout; a.dst[0] = dd; a.ndst = 1;
         a.bias = L.b >= 0 ? (const float*)(uintptr_t)16 : nullptr;   // presence only
         a.stat_slab = (float*)(uintptr_t)16;                          // (the rows are those of a TRAINING forward)
+        a.Wmaster = (const float*)(uintptr_t)16; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0;
         a.out_mode = L.head ? OUT_HEAD_NCHW : OUT_STORE;
         rows += conv_num_mtiles_flat(a, P->dtype);
       }
@@ -745,9 +746,10 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.nsrc = E.fill_srcs(L, a.src);
           a.W = fwd_weight(E, L);
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
+          if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0; }
           if (folded) {
             for (int i = 0; i < a.nsrc; ++i) { a.src[i].scale = nullptr; a.src[i].shift = nullptr; a.src[i].relu = 0; }
-            if (L.bn >= 0) { a.bias = E.bn_shift(L.bn); a.relu_out = P->bns[L.bn].lazy ? 1 : 0; }
+            if (L.bn >= 0) { a.bias = E.bn_shift(L.bn); a.relu_out = P->bns[L.bn].lazy ? 1 : 0; a.wscale = E.bn_scale(L.bn); }
           }
           a.ndst = 1;
           DstDesc d;
@@ -930,6 +932,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     a.src[0] = s; a.nsrc = 1;
     a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero
     a.W = E.ws + L.wimg_dgrad_off;
+    if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 1; }
     for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
     a.ndst = nd;
     a.out_mode = OUT_STORE;   // per-destination accumulate flags decide
@@ -1373,6 +1376,7 @@ int octseg_conv2d_forward(int dtype, const void* x, const float* w, const float*
   for (auto& a : la) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.W = scratch; a.bias = bias;
+    if (!transposed) { a.Wmaster = w; a.wO = Cout; a.wI = Cin; a.wtrans = 0; }
     DstDesc d; d.ptr = y; d.C = Cout; d.c0 = 0; d.cn = Cout; d.H = g.OH; d.W = g.OW; d.accum = 0; d.pool = 0;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.stat_slab = nullptr; a.stamp = g_stamp;
     HIPCHK(launch_conv(dtype, a, st));
@@ -1398,6 +1402,7 @@ int octseg_conv2d_backward_data(int dtype, const void* dy, const float* w, void*
   for (auto& a : ld) {
     SrcDesc s; s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = Cout; s.c0 = 0; s.H = g.OH; s.W = g.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.Cin = Cout; a.W = scratch; a.bias = nullptr;
+    if (!transposed) { a.Wmaster = w; a.wO = Cout; a.wI = Cin; a.wtrans = 1; }
     DstDesc d; d.ptr = dx; d.C = Cin; d.c0 = 0; d.cn = Cin; d.H = H; d.W = W; d.accum = 1; d.pool = 0;
     a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_ACCUM; a.stat_slab = nullptr;
     HIPCHK(launch_conv(dtype, a, st));

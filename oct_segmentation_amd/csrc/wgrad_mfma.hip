@@ -511,6 +511,7 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a0, hipStream_t st) {
   if (dtype == DT_F16) return hipErrorInvalidValue;   // f16 is an eval-forward dtype
 
   if (a0.ntaps <= 0) return hipSuccess;
+  if (thin_wgrad_eligible(a0, dtype)) return launch_thin_wgrad(dtype, a0, st);
   WgradArgs a = a0;
   flatten_1x1(a);
   if (a.ntaps == 1 || a.ntaps == 4 || a.ntaps == 9) {

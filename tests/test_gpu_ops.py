@@ -39,6 +39,13 @@ CASES = [
     # the wide-N tile (256 output channels, K >= 256, >= 1024 workgroups) where the persistent kernel is not eligible: a 120 x 120 map
     # (7.5 tiles per side: ragged tiles in both directions)
     (16, 120, 120, 256, 256, 3, 1, 1, False),
+    # thin full-resolution layers (thin.hip, bf16; f32 stays on conv_mfma_kernel): 16 / 32 channels in, 16 / 32 out on >= 4096 pixels --
+    # weights as the MFMA A operand, persistent 32-pixel-wide tiles; ragged widths (72 = 2 x 32 + 8, 104 = 3 x 32 + 8) and heights
+    (2, 64, 96, 16, 16, 3, 1, 1, False),     # x_0_4.conv2 shape
+    (2, 64, 96, 32, 16, 3, 1, 1, False),     # x_0_4.conv1 shape (8-row tiles, 96-byte LDS pixels); its dgrad writes 32 channels
+    (1, 80, 72, 16, 32, 3, 1, 1, False),
+    (3, 40, 104, 32, 32, 3, 1, 1, False),    # x_0_3.conv2 shape: two output blocks both ways
+    (5, 112, 96, 16, 16, 3, 1, 1, False),    # 1050 tiles > 768 workgroups: some walk two tiles
 ]
 
 
@@ -112,7 +119,7 @@ def test_conv_bias_and_identity(cuda):
 
 
 # (CASES[17]: the persistent 3x3 kernel's head-of-tap variant, which the f16 instantiation uses)
-@pytest.mark.parametrize('case', [CASES[0], CASES[3], CASES[4], CASES[6], CASES[7], CASES[12], CASES[13], CASES[17]], ids=str)
+@pytest.mark.parametrize('case', [CASES[0], CASES[3], CASES[4], CASES[6], CASES[7], CASES[12], CASES[13], CASES[17], CASES[20], CASES[21]], ids=str)
 def test_conv_forward_f16(cuda, case):
     """IEEE half storage (OCTSEG_F16, the serving dtype of BASELINE config #5): forward of every conv family against torch on the
     same f16-quantised operands, f32 accumulate -> 2e-3 of the output scale; the backward entry points refuse the dtype."""
