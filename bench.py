@@ -28,6 +28,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before HIP initialises: see oct_segmentation_amd/_lib.py (side stream vs RCCL's streams)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
@@ -352,15 +353,18 @@ def main():
     model.train()
     net = model.model
     exchange = None
+    # diagnostics of the data-parallel step's own cost on one GPU (--force-exchange): leave one of its two parts out
+    no_bcast, no_exch = bool(os.environ.get('OCTSEG_BENCH_NO_BCAST')), bool(os.environ.get('OCTSEG_BENCH_NO_EXCHANGE'))
     if dp:
         broadcast_parameters(net)
-        exchange = GradientExchange(net, nslices=args.allreduce_slices)
+        if not no_exch:
+            exchange = GradientExchange(net, nslices=args.allreduce_slices)
     opt = model.configure_optimizers()
     img, mask = make_batch(B, classes, S, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)
 
     def step():
-        if dp:
+        if dp and not no_bcast:
             broadcast_buffers(net)  # torch-DDP broadcast_buffers=True
         # grad_scale 1/world + SUM all-reduce == DDP's gradient mean; the all-reduce runs slice by slice beside the backward
         loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
@@ -387,8 +391,11 @@ def main():
     if sampler is not None:
         sampler.start()
     t0 = time.perf_counter()
+    enq = 0.0
     for _ in range(args.steps):
+        te = time.perf_counter()
         loss = step()
+        enq += time.perf_counter() - te      # host time to ENQUEUE a step (no synchronisation inside): how far the host runs ahead
     barrier()
     dt = time.perf_counter() - t0
     power = sampler.stop() if sampler is not None else None
@@ -441,6 +448,7 @@ def main():
             'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+Dice+bwd+allreduce+{args.optimizer}',
                        'global_batch': global_batch, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
             'loss': round(loss_val, 6),
+            'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3),
             'power': power,
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',

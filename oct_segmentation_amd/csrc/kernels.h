@@ -134,6 +134,29 @@ struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, t
 hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
                            unsigned long long total, int fold, hipStream_t st);
 
+// fpn.hip: what the FPN decoder (smp decoders/fpn; reference configs/tune.yaml:9-18) adds -- GroupNorm(32) + ReLU (+ bilinear x2,
+// align_corners=True) forward / backward, the resample's adjoint, nearest-x2 fill, merge-add + Dropout2d, x4 bilinear of the logits.
+struct GnArgs {
+  const void* y;            // raw conv output [N][HW][C] T
+  const void* g; void* dy;  // backward: gradient w.r.t. relu(gn(y)) at y's resolution in, gradient w.r.t. y out (may alias)
+  void* out;                // forward: relu(gn(y)), resampled
+  const float* gamma; const float* beta; float* dgamma; float* dbeta;
+  float* part;              // [N][S][C][2] partial sums (S = gn_num_slabs(HW))
+  float* ss;                // [N][C][2]: scale = gamma * rstd, shift = beta - mean * scale
+  float* stat;              // [N][G][2]: mean, rstd
+  float* coef;              // [N][G][2]: backward group means
+  size_t HW; int C, G, cpg; float eps;
+};
+int gn_num_slabs(size_t HW);
+hipError_t launch_gn_forward(int dtype, const GnArgs& a, int N, int H, int W, int up, hipStream_t st);
+hipError_t launch_gn_backward(int dtype, const GnArgs& a, int N, hipStream_t st);
+hipError_t launch_bilinear_adjoint(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int up, hipStream_t st);   // gin [N][H][W][C] <- gout [N][H*up][W*up][C]
+hipError_t launch_up2_fill(int dtype, const void* in, void* out, int N, int H, int W, int C, hipStream_t st);                    // out [N][2H][2W][C] = nearest x2 of in
+hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const void* a2, const void* a3, const float* m, void* out, int N,
+                             size_t HW, int C, hipStream_t st);
+hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, void* gin, int N, size_t HW, int C, hipStream_t st);
+hipError_t launch_bilinear_nchw(const float* z, float* out, int NC, int H, int W, int up, hipStream_t st);                          // NCHW f32, align_corners=True
+
 // serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,
                                 const int* rows, const int* cols, hipStream_t st);

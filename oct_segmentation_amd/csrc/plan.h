@@ -14,6 +14,7 @@ struct TensorInfo {
   size_t goff;   // byte offset of its gradient buffer (valid when need_grad)
   bool need_grad;
   bool external; // logits / image: not in the workspace
+  int grad_alias = -1;  // >= 0: shares the gradient buffer of that tensor (the summands of a merge-add all receive the same gradient)
 };
 
 struct Value {   // what a consumer reads: tensor t, optionally through BN `bn` (scale/shift) lazily
@@ -39,6 +40,15 @@ struct BNInfo {
   int y;                    // tensor it normalises
 };
 
+// GroupNorm(32) + ReLU of the FPN decoder's Conv3x3GNReLU (smp decoders/fpn): per-(image, group) statistics, no running buffers
+struct GNInfo {
+  std::string name;
+  int C, G;
+  int gamma, beta;          // param indices
+  int y;                    // raw conv output it normalises
+  size_t part_off, ss_off, stat_off, coef_off;   // workspace byte offsets: partial sums, scale/shift [N][C][2], mean/rstd and backward means [N][G][2]
+};
+
 struct ConvSrc { Value v; int up; };
 
 struct ConvLayer {
@@ -55,9 +65,14 @@ struct ConvLayer {
   ConvPackInfo pk_fwd, pk_dgrad;         // their layouts (tile variant of the forward / dgrad launches)
   bool has_dgrad;
   int OP;                   // channel count of dy as the dgrad sees it (Cout rounded up to 16)
+  bool accum_out = false;   // the forward ADDS into an existing tensor (FPNBlock: nearest-x2 fill, then the skip conv accumulates)
 };
 
-enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL };
+enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
+              OP_UP2,        // out = nearest x2 of in (materialised; a skip conv accumulates into it)
+              OP_GN,         // out = resample(relu(groupnorm(in))), up = 1 | 2 (bilinear, align_corners)
+              OP_MERGE,      // out = (ins[0] + .. + ins[3]) * dropout keep mask
+              OP_UPLOGITS }; // logits = bilinear x head_up of the head's low-resolution output
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -68,6 +83,8 @@ struct Op {
   bool relu = true;
   int in = -1, out = -1;  // OP_MAXPOOL / OP_BN_ACT / OP_STEM_COL out
   int lane = 0;           // forward stream: 0 main, 1 side (decoder nodes that only need early encoder features)
+  int gn = -1, up = 1;    // OP_GN
+  int ins[4] = {-1, -1, -1, -1};   // OP_MERGE
 };
 
 }  // namespace octseg
@@ -79,7 +96,13 @@ struct octseg_plan {
   std::vector<octseg::ParamInfo> params;
   std::vector<octseg::BNInfo> bns;
   std::vector<octseg::ConvLayer> convs;
+  std::vector<octseg::GNInfo> gns;
   std::vector<octseg::Op> ops;
+  // FPN: the head runs at stride 4 into z4 (NCHW f32) and is resampled x4 into the logits; its gradient comes back through dz4
+  int head_up = 1;
+  size_t z4_off = 0, dz4_off = 0;
+  const float* dropout_keep = nullptr;   // device [B][128] of {0, 1}: Dropout2d keep pattern of the next training forward (caller-owned)
+  float dropout_p = 0.2f;
   size_t param_numel = 0, buffer_numel = 0;
   size_t ws_bytes = 0;
   size_t act_begin = 0, act_end = 0, grad_begin = 0, grad_end = 0;

@@ -1,5 +1,5 @@
 """Oracle networks: torch-CPU restatement of smp 0.3.3 Unet / UnetPlusPlus /
-Linknet over torchvision ResNet encoders (TEST INFRASTRUCTURE ONLY).
+Linknet / FPN over torchvision ResNet encoders (TEST INFRASTRUCTURE ONLY).
 
 The module tree reproduces the upstream attribute names so that
 ``state_dict()`` keys equal the ones a reference checkpoint holds
@@ -261,11 +261,93 @@ class LinknetDecoder(nn.Module):
         return x
 
 
+# ---- smp 0.3.3 decoders/fpn/decoder.py (sweep architecture `FPN`, reference configs/tune.yaml:9-18).  Restated from
+# the published package (absent here): FPNBlock = nearest x2 of the coarser pyramid level + 1x1 skip conv (with bias);
+# SegmentationBlock = Conv3x3GNReLU x max(1, n_upsamples), each 3x3 conv (no bias) + GroupNorm(32) + ReLU + bilinear x2
+# (align_corners=True) while upsampling; MergeBlock('add'); Dropout2d(0.2); head = 1x1 conv + UpsamplingBilinear2d(4).
+class Conv3x3GNReLU(nn.Module):
+    def __init__(self, cin, cout, upsample=False):
+        super().__init__()
+        self.upsample = upsample
+        self.block = nn.Sequential(
+            nn.Conv2d(cin, cout, (3, 3), stride=1, padding=1, bias=False),
+            nn.GroupNorm(32, cout),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):
+        x = self.block(x)
+        if self.upsample:
+            x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+        return x
+
+
+class FPNBlock(nn.Module):
+    def __init__(self, pyramid_channels, skip_channels):
+        super().__init__()
+        self.skip_conv = nn.Conv2d(skip_channels, pyramid_channels, kernel_size=1)
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+        return x + self.skip_conv(skip)
+
+
+class FPNSegmentationBlock(nn.Module):
+    def __init__(self, cin, cout, n_upsamples=0):
+        super().__init__()
+        blocks = [Conv3x3GNReLU(cin, cout, upsample=bool(n_upsamples))]
+        for _ in range(1, n_upsamples):
+            blocks.append(Conv3x3GNReLU(cout, cout, upsample=True))
+        self.block = nn.Sequential(*blocks)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class InjectableDropout2d(nn.Module):
+    """nn.Dropout2d(p) whose keep pattern can be supplied: ``mask`` [N, C] of {0, 1} -- kept channels are scaled by 1 / (1 - p)
+    exactly as torch does.  With no mask set it IS nn.functional.dropout2d (random in training, identity in eval)."""
+
+    def __init__(self, p=0.2):
+        super().__init__()
+        self.p = p
+        self.mask = None
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        if self.mask is None:
+            return F.dropout2d(x, self.p, True)
+        return x * (self.mask.to(x.dtype) / (1.0 - self.p))[:, :, None, None]
+
+
+class FPNDecoder(nn.Module):
+    def __init__(self, encoder_channels, pyramid_channels=256, segmentation_channels=128, dropout=0.2):
+        super().__init__()
+        enc = list(encoder_channels)[::-1]
+        self.out_channels = segmentation_channels
+        self.p5 = nn.Conv2d(enc[0], pyramid_channels, kernel_size=1)
+        self.p4 = FPNBlock(pyramid_channels, enc[1])
+        self.p3 = FPNBlock(pyramid_channels, enc[2])
+        self.p2 = FPNBlock(pyramid_channels, enc[3])
+        self.seg_blocks = nn.ModuleList([FPNSegmentationBlock(pyramid_channels, segmentation_channels, n) for n in (3, 2, 1, 0)])
+        self.dropout = InjectableDropout2d(dropout)
+
+    def forward(self, *features):
+        c2, c3, c4, c5 = features[-4:]
+        p5 = self.p5(c5)
+        p4 = self.p4(p5, c4)
+        p3 = self.p3(p4, c3)
+        p2 = self.p2(p3, c2)
+        pyramid = [blk(p) for blk, p in zip(self.seg_blocks, (p5, p4, p3, p2))]
+        return self.dropout(sum(pyramid))       # MergeBlock('add')
+
+
 class SegmentationHead(nn.Sequential):
-    def __init__(self, cin, cout, kernel_size):
+    def __init__(self, cin, cout, kernel_size, upsampling=1):
         super().__init__(
             nn.Conv2d(cin, cout, kernel_size, padding=kernel_size // 2),
-            nn.Identity(),
+            nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity(),
             nn.Identity(),
         )
 
@@ -303,6 +385,9 @@ class SegmentationModel(nn.Module):
         elif arch == 'linknet':
             self.decoder = LinknetDecoder(ch)
             self.segmentation_head = SegmentationHead(32, classes, 1)
+        elif arch == 'fpn':
+            self.decoder = FPNDecoder(ch)
+            self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 1, upsampling=4)
         else:
             raise KeyError(arch)
         _init_decoder(self.decoder)
@@ -317,7 +402,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):
