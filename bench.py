@@ -40,6 +40,7 @@ WORKLOADS = {
     'linknet_r50_704': ('linknet', 'resnet50', 2, 704),
     'unet_r50_704': ('unet', 'resnet50', 1, 704),
     'unet_r18_256': ('unet', 'resnet18', 1, 256),
+    'fpn_r50_704': ('fpn', 'resnet50', 1, 704),       # a sweep architecture outside BASELINE's three
 }
 
 
@@ -292,6 +293,8 @@ def main():
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)')
+    ap.add_argument('--train-graph', action='store_true',
+                    help='forward + Dice + backward of a step as one replayed hipGraph (octseg_net_train_step); N = 1 or without the exchange')
     ap.add_argument('--force-exchange', action='store_true',
                     help='N = 1: run the data-parallel step anyway -- a one-rank RCCL group, buffer broadcast and the sliced all-reduce '
                          'beside the backward (exercises the nccl branch on a single GPU; the collectives are identities)')
@@ -352,6 +355,7 @@ def main():
                                  input_size=S, device=dev, compute_dtype=cdt, seed=1234)
     model.train()
     net = model.model
+    net.use_train_graph = bool(args.train_graph)
     exchange = None
     # diagnostics of the data-parallel step's own cost on one GPU (--force-exchange): leave one of its two parts out
     no_bcast, no_exch = bool(os.environ.get('OCTSEG_BENCH_NO_BCAST')), bool(os.environ.get('OCTSEG_BENCH_NO_EXCHANGE'))
@@ -407,6 +411,7 @@ def main():
     # part of the decoder run on a side stream; brackets taken there also contain the time a kernel shares the chip.
     prof_alone = (C.c_double * 12)()
     n_alone = 2
+    net.use_train_graph = False          # the roofline pass brackets every launch: eager, one stream
     L.check(L.lib().octseg_debug_set_serial(1))
     step()
     barrier()
@@ -478,6 +483,8 @@ def main():
                 'sclk_mhz': mhz, 'quoted_mhz': 2400, 'frac_at_granted_clock': round(ach / (peak * mhz / 2400.0), 4),
                 'note': 'hwmon freq1_input averaged over the timed steps of THIS run (a step alternates power-capped conv loops with HBM '
                         'sweeps, so the conv loops themselves run below this average); `peak` is the 2.4 GHz figure'}
+        if args.train_graph:
+            out['config']['train_graph'] = 'forward + Dice + backward replayed as one hipGraph per step (octseg_net_train_step)'
         if args.force_exchange:
             out['config']['force_exchange'] = f'one-rank {args.backend} group: buffer broadcast + {args.allreduce_slices}-slice all-reduce issued beside the backward'
         # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)

@@ -6,6 +6,7 @@
  *
  *   octseg_plan_create / _destroy      smp.create_model(arch, encoder_name, in_channels, classes)
  *                                      src/models/smp/model.py:38-44
+ *   octseg_plan_set_dropout            the nn.Dropout2d inside smp's FPN decoder (arch "fpn"): its keep pattern, injected
  *   octseg_plan_param_info / bn_info   the nn.Module parameter / buffer tree behind state_dict()
  *                                      (load_from_checkpoint, src/predict.py:39-48)
  *   octseg_net_forward                 OCTSegmentationModel.forward (normalize=1, model.py:65-71) and
@@ -14,6 +15,7 @@
  *                                      (model.py:55,81,115) + smp.metrics.get_stats (utils.py:19-23)
  *   octseg_net_backward                loss.backward() that Lightning runs after training_step
  *                                      (model.py:73-95, train.py:130-133)
+ *   octseg_net_train_step              training_step + loss.backward() as one call, optionally one replayed hipGraph (model.py:73-95)
  *   octseg_net_backward_sliced         the same under DDP: gradient buckets handed out while the backward still runs
  *                                      (train.py:122-133, devices > 1)
  *   octseg_optim_step                  configure_optimizers -> SGD|RMSprop|RAdam|Adam.step()
@@ -58,7 +60,7 @@ typedef enum {
 typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
-  const char* arch;     /* "unet" | "unetplusplus" | "linknet" (case-insensitive) */
+  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" (case-insensitive) */
   const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
   int classes;          /* output channels */
   int batch, height, width;
@@ -118,6 +120,11 @@ int octseg_profile_stop(double* out);
  * changes the parameter arena in place: optimizer.step(), load_state_dict(), an all-reduce of parameters. */
 int octseg_plan_params_changed(octseg_plan* plan);
 
+/* arch "fpn" (smp FPN, one of the reference's sweep architectures: configs/tune.yaml:9-18 through smp.create_model, model.py:38-44):
+ * the Dropout2d(0.2) behind the merge needs a keep pattern in training -- device float [batch][128] of 0 / 1, caller-owned, read by the
+ * next training forward AND its backward (kept channels are scaled by 1 / (1 - 0.2), torch's Dropout2d).  Eval forwards ignore it. */
+int octseg_plan_set_dropout(octseg_plan* plan, const float* keep_dev);
+
 /* Serving path (reference: src/models/smp/predict.py segment(), model.py:183-200 predict()): enable = 1 makes every
  * eval-mode octseg_net_forward of this plan run as a hipGraph -- the first call with a given argument set runs
  * eagerly, the second is captured, later ones replay it (one launch instead of ~400) for as long as the pointers,
@@ -158,6 +165,16 @@ int octseg_dice_forward(octseg_plan* plan, void* workspace, const float* logits,
  * grads (fp32 arena, same layout as params) is overwritten with d(grad_scale * loss)/dparams. */
 int octseg_net_backward(octseg_plan* plan, const float* params, float* grads, void* workspace,
                         const float* logits, const float* target, float grad_scale, void* stream);
+
+/* Forward (train) + Dice + backward in ONE call (reference: training_step + loss.backward(), src/models/smp/model.py:73-95 under Lightning).
+ * Same launches as octseg_net_forward(train = 1) -> octseg_dice_forward -> octseg_net_backward.  octseg_plan_set_train_graph(plan, 1):
+ * the call is captured into a hipGraph on its second use with an unchanged argument set (every pointer, the stream, the constants) and
+ * replayed afterwards -- one launch per step instead of ~800 (keep image / target / logits / loss / stats in persistent buffers).
+ * Not available together with the sliced (data-parallel) backward. */
+int octseg_net_train_step(octseg_plan* plan, const float* params, float* grads, float* buffers, void* workspace, const float* image,
+                          const float* target, float* logits, float* loss, long long* stats, int normalize, const float* mean,
+                          const float* stdv, float grad_scale, void* stream);
+int octseg_plan_set_train_graph(octseg_plan* plan, int enable);
 
 /* Data-parallel variant (reference: torch DDP's bucketed gradient all-reduce overlapped with backward, which Lightning installs for
  * src/models/smp/train.py:122-133 when more than one GPU is visible).  Same launches; the gradient arena is cut into

@@ -261,10 +261,10 @@ __global__ __launch_bounds__(256) void bilinear_adjoint_kernel(const void* gout,
   }
 }
 
-// out = (a0 + a1 + a2 + a3) * m[n][c]   (MergeBlock('add') + Dropout2d; m = keep / (1 - p) in training, nullptr = identity)
+// out = (a0 + a1 + a2 + a3) * m[n][c] * mscale   (MergeBlock('add') + Dropout2d; m = keep pattern, mscale = 1 / (1 - p); nullptr = identity)
 template <typename T>
 __global__ __launch_bounds__(256) void merge_drop_kernel(const void* a0, const void* a1, const void* a2, const void* a3, const float* m,
-                                                         void* out, size_t HW, int C, size_t nvec) {
+                                                         float mscale, void* out, size_t HW, int C, size_t nvec) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC;
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -283,14 +283,14 @@ __global__ __launch_bounds__(256) void merge_drop_kernel(const void* a0, const v
       const int c = (int)(v % vpc) * VEC;
       const size_t n = v / (HW * vpc);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) x[i] *= m[n * C + c + i];
+      for (int i = 0; i < VEC; ++i) x[i] *= m[n * C + c + i] * mscale;
     }
     stv<T>(out, v, EV<T>::pack(x));
   }
 }
 // gin = gout * m[n][c]
 template <typename T>
-__global__ __launch_bounds__(256) void drop_bwd_kernel(const void* gout, const float* m, void* gin, size_t HW, int C, size_t nvec) {
+__global__ __launch_bounds__(256) void drop_bwd_kernel(const void* gout, const float* m, float mscale, void* gin, size_t HW, int C, size_t nvec) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = C / VEC;
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void drop_bwd_kernel(const void* gout, const f
       const int c = (int)(v % vpc) * VEC;
       const size_t n = v / (HW * vpc);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) x[i] *= m[n * C + c + i];
+      for (int i = 0; i < VEC; ++i) x[i] *= m[n * C + c + i] * mscale;
     }
     stv<T>(gin, v, EV<T>::pack(x));
   }
@@ -372,15 +372,15 @@ hipError_t launch_bilinear_adjoint(int dtype, const void* gout, void* gin, int N
   else hipLaunchKernelGGL(bilinear_adjoint_kernel<bf16_t>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, gout, gin, N, H, W, C, up, sy, sx, isy, isx);
   return hipGetLastError();
 }
-hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const void* a2, const void* a3, const float* m, void* out, int N,
-                             size_t HW, int C, hipStream_t st) {
+hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const void* a2, const void* a3, const float* m, float mscale, void* out,
+                             int N, size_t HW, int C, hipStream_t st) {
   const size_t nvec = (size_t)N * HW * (C / (dtype == DT_F32 ? 4 : 8));
-  FPN_DISPATCH(merge_drop_kernel, dim3(grid_for(nvec, 256)), a0, a1, a2, a3, m, out, HW, C, nvec);
+  FPN_DISPATCH(merge_drop_kernel, dim3(grid_for(nvec, 256)), a0, a1, a2, a3, m, mscale, out, HW, C, nvec);
   return hipGetLastError();
 }
-hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, void* gin, int N, size_t HW, int C, hipStream_t st) {
+hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, float mscale, void* gin, int N, size_t HW, int C, hipStream_t st) {
   const size_t nvec = (size_t)N * HW * (C / (dtype == DT_F32 ? 4 : 8));
-  FPN_DISPATCH(drop_bwd_kernel, dim3(grid_for(nvec, 256)), gout, m, gin, HW, C, nvec);
+  FPN_DISPATCH(drop_bwd_kernel, dim3(grid_for(nvec, 256)), gout, m, mscale, gin, HW, C, nvec);
   return hipGetLastError();
 }
 hipError_t launch_bilinear_nchw(const float* z, float* out, int NC, int H, int W, int up, hipStream_t st) {

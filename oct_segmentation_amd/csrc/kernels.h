@@ -152,9 +152,9 @@ hipError_t launch_gn_forward(int dtype, const GnArgs& a, int N, int H, int W, in
 hipError_t launch_gn_backward(int dtype, const GnArgs& a, int N, hipStream_t st);
 hipError_t launch_bilinear_adjoint(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int up, hipStream_t st);   // gin [N][H][W][C] <- gout [N][H*up][W*up][C]
 hipError_t launch_up2_fill(int dtype, const void* in, void* out, int N, int H, int W, int C, hipStream_t st);                    // out [N][2H][2W][C] = nearest x2 of in
-hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const void* a2, const void* a3, const float* m, void* out, int N,
-                             size_t HW, int C, hipStream_t st);
-hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, void* gin, int N, size_t HW, int C, hipStream_t st);
+hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const void* a2, const void* a3, const float* m, float mscale, void* out,
+                             int N, size_t HW, int C, hipStream_t st);
+hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, float mscale, void* gin, int N, size_t HW, int C, hipStream_t st);
 hipError_t launch_bilinear_nchw(const float* z, float* out, int NC, int H, int W, int up, hipStream_t st);                          // NCHW f32, align_corners=True
 
 // serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel

@@ -37,6 +37,7 @@ static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; std::string name; };
 bool g_prof_on = false;
+bool g_capturing = false;   // a stream capture is in progress on this thread's call: no timing events inside it
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t prof_event() {
@@ -48,7 +49,7 @@ hipEvent_t prof_event() {
 static bool g_prof_hbm = false;   // set with octseg_debug_set_serial
 struct ProfScope {
   hipStream_t st; ProfRec r; bool on;
-  ProfScope(int kind, double flops, hipStream_t s, const std::string& name = std::string()) : st(s), on(g_prof_on) {
+  ProfScope(int kind, double flops, hipStream_t s, const std::string& name = std::string()) : st(s), on(g_prof_on && !g_capturing) {
     if (kind == 3 && !g_prof_hbm) on = false;   // the BatchNorm sweeps are only bracketed in the one-stream measurement pass
     if (!on) return;
     r.kind = kind; r.flops = flops; r.name = name; r.a = prof_event(); r.b = prof_event();
@@ -245,7 +246,7 @@ struct Builder {
   // conv (+ optional BN whose statistics the epilogue emits).  Returns Value{raw output, bn}.
   Value conv(const std::string& name, const std::vector<ConvSrc>& srcs, int Cout, int R, int stride, int pad,
              const std::string& bn_name, bool bias, bool transposed = false, bool head = false,
-             bool stem = false, bool bn_lazy = true) {
+             bool stem = false, bool bn_lazy = true, int accum_into = -1) {
     ConvLayer L;
     L.name = name; L.R = R; L.S = R; L.stride = stride; L.pad = pad;
     L.transposed = transposed; L.head = head; L.stem = stem; L.srcs = srcs; L.Cout = Cout;
@@ -260,7 +261,8 @@ struct Builder {
     else L.w = param(name + ".weight", transposed ? OCTSEG_P_CONVT : OCTSEG_P_CONV, R, R, Cout, Cin, 0);
     L.b = bias ? param(name + ".bias", OCTSEG_P_VEC, 1, 1, Cout, 1, 0) : -1;
     L.OP = (Cout + 15) / 16 * 16;
-    L.out = head ? -1 : tensor(L.N, L.OH, L.OW, Cout);
+    L.out = head ? -1 : (accum_into >= 0 ? accum_into : tensor(L.N, L.OH, L.OW, Cout));
+    L.accum_out = accum_into >= 0;
     L.bn = -1; L.wimg_fwd_off = L.wimg_dgrad_off = 0; L.has_dgrad = false;
     P->convs.push_back(L);
     const int ci = (int)P->convs.size() - 1;
@@ -293,6 +295,35 @@ struct Builder {
     const TensorInfo& t = P->tensors[in];
     const int o = tensor(t.N, t.H / 2, t.W / 2, t.C);
     Op op; op.kind = OP_MAXPOOL; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  // ---- FPN decoder pieces (smp decoders/fpn/decoder.py, restated in oracle/nets.py)
+  int up2(int in) {   // F.interpolate(x, scale_factor=2, mode='nearest'), materialised: the FPNBlock's skip conv accumulates into it
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H * 2, t.W * 2, t.C);
+    Op op; op.kind = OP_UP2; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int gn_act(const std::string& name, int y, int up) {   // GroupNorm(32) + ReLU (+ bilinear x2, align_corners=True)
+    const TensorInfo& t = P->tensors[y];
+    GNInfo g;
+    g.name = name; g.C = t.C; g.G = 32; g.y = y;
+    g.gamma = param(name + ".weight", OCTSEG_P_VEC, 1, 1, t.C, 1, 0);
+    g.beta = param(name + ".bias", OCTSEG_P_VEC, 1, 1, t.C, 1, 0);
+    g.part_off = g.ss_off = g.stat_off = g.coef_off = 0;
+    P->gns.push_back(g);
+    const int o = tensor(t.N, t.H * up, t.W * up, t.C);
+    Op op; op.kind = OP_GN; op.in = y; op.out = o; op.gn = (int)P->gns.size() - 1; op.up = up;
+    P->ops.push_back(op);
+    return o;
+  }
+  int merge4(const int (&ins)[4]) {   // MergeBlock('add') + Dropout2d: every summand receives the same gradient -> one shared buffer
+    const TensorInfo& t = P->tensors[ins[0]];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_MERGE; op.out = o;
+    for (int i = 0; i < 4; ++i) { op.ins[i] = ins[i]; if (i > 0) P->tensors[ins[i]].grad_alias = ins[0]; }
     P->ops.push_back(op);
     return o;
   }
@@ -482,12 +513,38 @@ static int build_plan(octseg_plan* P) {
       if (i < 4) x = mat(b.bn_act(v3, Value(), fr[i + 1], true));
       else x = v3;
     }
+  } else if (P->arch == "fpn") {
+    // smp FPN (reference sweep, configs/tune.yaml:9-18): pyramid_channels 256, segmentation_channels 128, merge 'add', Dropout2d(0.2),
+    // head = 1x1 conv at stride 4 + UpsamplingBilinear2d(4).  f[1..4] = c2..c5 (strides 4..32).
+    head_k = 1;
+    P->head_up = 4;
+    int pyr[4];
+    pyr[0] = b.conv("decoder.p5", {{mat(f[4]), 0}}, 256, 1, 1, 0, "", true).t;
+    const char* lvl[3] = {"decoder.p4", "decoder.p3", "decoder.p2"};
+    for (int i = 0; i < 3; ++i) {
+      const int up = b.up2(pyr[i]);
+      b.conv(std::string(lvl[i]) + ".skip_conv", {{mat(f[3 - i]), 0}}, 256, 1, 1, 0, "", true, false, false, false, true, up);
+      pyr[i + 1] = up;
+    }
+    int seg[4];
+    for (int i = 0; i < 4; ++i) {
+      const int nup = 3 - i, nblk = nup > 1 ? nup : 1;
+      int t = pyr[i];
+      for (int j = 0; j < nblk; ++j) {
+        const std::string pre = "decoder.seg_blocks." + std::to_string(i) + ".block." + std::to_string(j) + ".block";
+        const Value y = b.conv(pre + ".0", {{mat(t), 0}}, 128, 3, 1, 1, "", false);
+        t = b.gn_act(pre + ".1", y.t, nup > 0 ? 2 : 1);
+      }
+      seg[i] = t;
+    }
+    x = mat(b.merge4(seg));
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
+  if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  assign_lanes(P);
+  if (P->arch != "fpn") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -498,8 +555,23 @@ static int build_plan(octseg_plan* P) {
   P->act_end = off;
   P->grad_begin = off;
   for (auto& t : P->tensors)
-    if (t.need_grad) { t.goff = off; off += align_up((size_t)t.N * t.H * t.W * t.C * esz); }
+    if (t.need_grad && t.grad_alias < 0) { t.goff = off; off += align_up((size_t)t.N * t.H * t.W * t.C * esz); }
+  for (auto& t : P->tensors)
+    if (t.need_grad && t.grad_alias >= 0) t.goff = P->tensors[t.grad_alias].goff;
   P->grad_end = off;
+  for (auto& g : P->gns) {
+    const TensorInfo& t = P->tensors[g.y];
+    const size_t S = (size_t)gn_num_slabs((size_t)t.H * t.W);
+    g.part_off = off; off += align_up((size_t)t.N * S * g.C * 2 * sizeof(float));
+    g.ss_off = off; off += align_up((size_t)t.N * g.C * 2 * sizeof(float));
+    g.stat_off = off; off += align_up((size_t)t.N * g.G * 2 * sizeof(float));
+    g.coef_off = off; off += align_up((size_t)t.N * g.G * 2 * sizeof(float));
+  }
+  if (P->head_up > 1) {
+    const size_t h4 = P->H / P->head_up, w4 = P->W / P->head_up;
+    P->z4_off = off; off += align_up((size_t)P->B * P->classes * h4 * w4 * sizeof(float));
+    P->dz4_off = off; off += align_up((size_t)P->B * h4 * w4 * 16 * esz);
+  }
   for (auto& bn : P->bns) { bn.ss_off = off; off += align_up((size_t)bn.C * 6 * sizeof(float)); }
   size_t slab = 0, tmp = 0;
   for (auto& L : P->convs) {
@@ -615,6 +687,18 @@ struct Exec {
   float* bn_rstd(int bn) const { return ss(bn) + 3 * P->bns[bn].C; }
   float* bn_coef(int bn) const { return ss(bn) + 4 * P->bns[bn].C; }
 
+  GnArgs gn_args(int gi) const {
+    const GNInfo& g = P->gns[gi];
+    const TensorInfo& t = P->tensors[g.y];
+    GnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y = act(g.y);
+    a.gamma = params + P->params[g.gamma].off; a.beta = params + P->params[g.beta].off;
+    if (grads) { a.dgamma = grads + P->params[g.gamma].off; a.dbeta = grads + P->params[g.beta].off; }
+    a.part = (float*)(ws + g.part_off); a.ss = (float*)(ws + g.ss_off); a.stat = (float*)(ws + g.stat_off); a.coef = (float*)(ws + g.coef_off);
+    a.HW = (size_t)t.H * t.W; a.C = g.C; a.G = g.G; a.cpg = g.C / g.G; a.eps = 1e-5f;
+    return a;
+  }
   Geom geom(const ConvLayer& L) const {
     Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
     if (L.stem) { g.R = g.S = 1; g.pad = 0; }
@@ -753,8 +837,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           }
           a.ndst = 1;
           DstDesc d;
-          d.accum = 0; d.pool = 0;
-          if (L.head) { d.ptr = logits; d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW; }
+          d.accum = L.accum_out ? 1 : 0; d.pool = 0;
+          if (L.head) {   // NCHW f32: the caller's logits, or (FPN) the stride-4 map that OP_UPLOGITS resamples
+            d.ptr = P->head_up > 1 ? (void*)(E.ws + P->z4_off) : (void*)logits;
+            d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW;
+          }
           else { d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE; }
           a.dst[0] = d;
           a.stat_slab = (L.bn >= 0 && E.train) ? slab_l : nullptr;
@@ -803,6 +890,32 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           HIPCHK(launch_bn_act(P->dtype, a, st));
         }
         tseq[op.out] = stamp;
+        break;
+      }
+      case OP_UP2: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_up2_fill(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, st));
+        break;
+      }
+      case OP_GN: {
+        const TensorInfo& t = P->tensors[op.in];
+        const GnArgs ga = E.gn_args(op.gn);
+        GnArgs a2 = ga;
+        a2.out = E.act(op.out);
+        HIPCHK(launch_gn_forward(P->dtype, a2, t.N, t.H, t.W, op.up, st));
+        break;
+      }
+      case OP_MERGE: {
+        const TensorInfo& t = P->tensors[op.out];
+        if (E.train && P->dropout_keep == nullptr)
+          return fail(OCTSEG_BAD_ARG, "FPN training forward: no Dropout2d keep mask set (octseg_plan_set_dropout: device float [B][128] of 0 / 1)");
+        HIPCHK(launch_merge_drop(P->dtype, E.act(op.ins[0]), E.act(op.ins[1]), E.act(op.ins[2]), E.act(op.ins[3]),
+                                 E.train ? P->dropout_keep : nullptr, 1.0f / (1.0f - P->dropout_p), E.act(op.out), t.N, (size_t)t.H * t.W, t.C, st));
+        break;
+      }
+      case OP_UPLOGITS: {
+        const int h4 = P->H / P->head_up, w4 = P->W / P->head_up;
+        HIPCHK(launch_bilinear_nchw((const float*)(E.ws + P->z4_off), logits, P->B * P->classes, h4, w4, P->head_up, st));
         break;
       }
       case OP_MAXPOOL: {
@@ -982,6 +1095,7 @@ static void slice_plan(const octseg_plan* P, SliceCtx& S) {
     const Op& op = P->ops[oi];
     if (op.kind == OP_CONV) { touch(oi, P->convs[op.conv].w); touch(oi, P->convs[op.conv].b); }
     else if (op.kind == OP_BN_FIN) { if (P->bns[op.bn].lazy) { touch(oi, P->bns[op.bn].gamma); touch(oi, P->bns[op.bn].beta); } }
+    else if (op.kind == OP_GN) { touch(oi, P->gns[op.gn].gamma); touch(oi, P->gns[op.gn].beta); }
     else if (op.kind == OP_BN_ACT) {
       touch(oi, P->bns[op.y.bn].gamma); touch(oi, P->bns[op.y.bn].beta);
       if (op.res.t >= 0 && op.res.bn >= 0) { touch(oi, P->bns[op.res.bn].gamma); touch(oi, P->bns[op.res.bn].beta); }
@@ -1034,7 +1148,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
       case OP_STEM_COL: break;
       case OP_CONV: {
         const ConvLayer& L = P->convs[op.conv];
-        if (L.head) rc = conv_backward(E, L, E.ws + P->dlogits_off, P->dlogits_C);
+        if (L.head) rc = conv_backward(E, L, E.ws + (P->head_up > 1 ? P->dz4_off : P->dlogits_off), P->dlogits_C);
         else rc = conv_backward(E, L, E.grad(L.out), L.Cout);
         if (rc) return rc;
         break;
@@ -1078,6 +1192,38 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
           const int acc = E.claim(op.post);
           HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, acc ? 0 : 1, E.st));
         }
+        break;
+      }
+      case OP_UPLOGITS: {   // adjoint of the x4 bilinear resample: dL/dlogits (NHWC, padded channels) -> gradient of the stride-4 map
+        const int h4 = P->H / P->head_up, w4 = P->W / P->head_up;
+        HIPCHK(launch_bilinear_adjoint(P->dtype, E.ws + P->dlogits_off, E.ws + P->dz4_off, P->B, h4, w4, P->dlogits_C, P->head_up, E.st));
+        break;
+      }
+      case OP_MERGE: {      // every summand's gradient = dropout mask * gradient of the sum: written once into the shared buffer
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_drop_bwd(P->dtype, E.grad(op.out), P->dropout_keep, 1.0f / (1.0f - P->dropout_p), E.grad(op.ins[0]), t.N, (size_t)t.H * t.W,
+                               t.C, E.st));
+        for (int i = 0; i < 4; ++i) E.ginit[op.ins[i]] = 1;
+        break;
+      }
+      case OP_GN: {
+        const TensorInfo& t = P->tensors[op.in];
+        GnArgs ga = E.gn_args(op.gn);
+        if (op.up > 1) {      // gradient w.r.t. relu(gn(y)) at y's resolution: adjoint of the bilinear x2, parked in y's gradient buffer
+          HIPCHK(launch_bilinear_adjoint(P->dtype, E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, op.up, E.st));
+          ga.g = E.grad(op.in);
+        } else {
+          ga.g = E.grad(op.out);
+        }
+        ga.dy = E.grad(op.in);
+        E.ginit[op.in] = 1;
+        HIPCHK(launch_gn_backward(P->dtype, ga, t.N, E.st));
+        break;
+      }
+      case OP_UP2: {        // gradient of the nearest x2: 2x2 sums into the coarser level
+        const TensorInfo& t = P->tensors[op.in];
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(op.in), E.grad(op.out), t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
         break;
       }
       case OP_MAXPOOL: {
@@ -1137,6 +1283,7 @@ int octseg_plan_destroy(octseg_plan* p) {
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->ev_slice) (void)hipEventDestroy(p->ev_slice);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->tgraph_exec) (void)hipGraphExecDestroy(p->tgraph_exec);
   }
   delete p;
   return OCTSEG_OK;
@@ -1258,6 +1405,15 @@ int octseg_plan_set_graph(octseg_plan* p, int enable) {
   return OCTSEG_OK;
 }
 
+// FPN's Dropout2d(0.2) (smp decoders/fpn: self.dropout after the merge): the keep pattern of the NEXT training forward(s), device float
+// [B][128] of 0 / 1 (kept channels are scaled by 1 / (1 - p) as torch does).  The caller draws it (the reference's pattern comes from
+// torch's global RNG and is not reproducible across implementations anyway); the backward reuses the same pointer.
+int octseg_plan_set_dropout(octseg_plan* p, const float* keep_dev) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  p->dropout_keep = keep_dev;
+  return OCTSEG_OK;
+}
+
 // Training-input augmentation on the GPU (dataset.py:160-207): see augment.hip.  img [B,3,H,W] f32 BGR 0..255, mask
 // [B,classes,H,W] f32 0/1, params device f32 [B][OCTSEG_AUG_NPARAM]; outputs must not alias the inputs.
 int octseg_augment(const float* img, const float* mask, float* img_out, float* mask_out, const float* params, int B, int classes, int H,
@@ -1299,6 +1455,65 @@ int octseg_net_backward(octseg_plan* p, const float* params, float* grads, void*
   if (p->dtype == OCTSEG_F16) return fail(OCTSEG_BAD_DTYPE, "f16 is a serving dtype: no backward");
   Exec E{p, params, grads, nullptr, (char*)workspace, (hipStream_t)stream, 1};
   return run_backward(E, logits, target, grad_scale);
+}
+
+// One training step's device work in one call: forward (batch statistics) + Dice (+ confusion counts) + backward -- what training_step
+// and loss.backward() enqueue in the reference (src/models/smp/model.py:73-95, Lightning's automatic optimisation).  With
+// octseg_plan_set_train_graph(plan, 1) the call is captured into a hipGraph (second call with an unchanged argument set) and replayed:
+// the ~800 launches, the weight-gradient side stream, the forward lane and their event edges become ONE launch -- the host cost of a
+// step drops from tens of milliseconds of enqueueing to microseconds, which is what small per-GPU batches (strong scaling) need.
+// The replay runs the very launches of the eager call (weight images are repacked inside: the parameters change every step).
+int octseg_net_train_step(octseg_plan* p, const float* params, float* grads, float* buffers, void* workspace, const float* image,
+                          const float* target, float* logits, float* loss, long long* stats, int normalize, const float* mean,
+                          const float* stdv, float grad_scale, void* stream) {
+  if (!p || !params || !grads || !buffers || !workspace || !image || !target || !logits || !loss)
+    return fail(OCTSEG_BAD_ARG, "null argument");
+  if (normalize && (!mean || !stdv)) return fail(OCTSEG_BAD_ARG, "normalize=1 needs mean/std");
+  if (p->dtype == OCTSEG_F16) return fail(OCTSEG_BAD_DTYPE, "f16 is a serving dtype (eval forwards, reference predict.py); train in bf16 or f32");
+  hipStream_t st = (hipStream_t)stream;
+  auto body = [&]() -> int {
+    Exec Ef{p, params, nullptr, buffers, (char*)workspace, st, 1};
+    int rc = run_forward(Ef, image, logits, normalize, mean, stdv);
+    if (rc) return rc;
+    DiceArgs a;
+    memset(&a, 0, sizeof(a));
+    a.logits = logits; a.target = target; a.B = p->B; a.C = p->classes; a.HW = (size_t)p->H * p->W;
+    a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss;
+    HIPCHK(launch_dice_fwd(a, st));
+    Exec Eb{p, params, grads, nullptr, (char*)workspace, st, 1};
+    return run_backward(Eb, logits, target, grad_scale);
+  };
+  if (!p->tgraph_enabled || serial_mode()) return body();
+  octseg_plan::TrainKey key{params, grads, buffers, workspace, image, target, logits, loss, stats, stream, p->dropout_keep,
+                            normalize, {0, 0, 0}, {1, 1, 1}, grad_scale};
+  if (normalize) for (int i = 0; i < 3; ++i) { key.mean[i] = mean[i]; key.stdv[i] = stdv[i]; }
+  if (!(key == p->tgraph_key)) {
+    if (p->tgraph_exec) { (void)hipGraphExecDestroy(p->tgraph_exec); p->tgraph_exec = nullptr; }
+    p->tgraph_key = key; p->tgraph_seen = 0;
+  }
+  if (p->tgraph_exec) { HIPCHK(hipGraphLaunch(p->tgraph_exec, st)); return OCTSEG_OK; }
+  if (p->tgraph_seen++ == 0) return body();   // eager warm-up: function attributes, job tables, side stream and events exist afterwards
+  p->packed_valid = false;                    // the captured step must contain the weight packing (a replay meets new parameters)
+  hipGraph_t g = nullptr;
+  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  g_capturing = true;
+  const int rc = body();
+  g_capturing = false;
+  const hipError_t ce = hipStreamEndCapture(st, &g);
+  p->packed_valid = false;                    // (nothing was executed: the images in the workspace are whatever the last real step left)
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (ce != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail(OCTSEG_HIP_ERROR, std::string("training-step capture: ") + hipGetErrorString(ce)); }
+  const hipError_t ie = hipGraphInstantiate(&p->tgraph_exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie != hipSuccess) { p->tgraph_exec = nullptr; return fail(OCTSEG_HIP_ERROR, hipGetErrorString(ie)); }
+  HIPCHK(hipGraphLaunch(p->tgraph_exec, st));
+  return OCTSEG_OK;
+}
+int octseg_plan_set_train_graph(octseg_plan* p, int enable) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  p->tgraph_enabled = enable != 0;
+  if (!enable && p->tgraph_exec) { (void)hipGraphExecDestroy(p->tgraph_exec); p->tgraph_exec = nullptr; p->tgraph_seen = 0; }
+  return OCTSEG_OK;
 }
 
 // Data-parallel backward: the same launches as octseg_net_backward; the gradient arena is cut into `nslices` contiguous,

@@ -149,4 +149,19 @@ struct octseg_plan {
              mean[2] == o.mean[2] && stdv[0] == o.stdv[0] && stdv[1] == o.stdv[1] && stdv[2] == o.stdv[2];
     }
   } graph_key{};
+  // the TRAINING step (forward + Dice + backward, octseg_net_train_step) as one hipGraph: ~800 launches, two streams and their event
+  // edges become one launch; captured on the second call with an unchanged argument set, replayed while the set stays the same
+  bool tgraph_enabled = false;
+  int tgraph_seen = 0;
+  hipGraphExec_t tgraph_exec = nullptr;
+  struct TrainKey {
+    const void *params, *grads, *buffers, *ws, *image, *target, *logits, *loss, *stats, *stream, *dropout;
+    int normalize; float mean[3], stdv[3], grad_scale;
+    bool operator==(const TrainKey& o) const {
+      return params == o.params && grads == o.grads && buffers == o.buffers && ws == o.ws && image == o.image && target == o.target &&
+             logits == o.logits && loss == o.loss && stats == o.stats && stream == o.stream && dropout == o.dropout &&
+             normalize == o.normalize && grad_scale == o.grad_scale && mean[0] == o.mean[0] && mean[1] == o.mean[1] &&
+             mean[2] == o.mean[2] && stdv[0] == o.stdv[0] && stdv[1] == o.stdv[1] && stdv[2] == o.stdv[2];
+    }
+  } tgraph_key{};
 };

@@ -16,7 +16,8 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn')
+_FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152')
 
 
@@ -153,12 +154,16 @@ class SegNet(nn.Module):
 
     # smp.create_model keywords this engine implements at their smp 0.3.3 defaults only (anything else changes the graph)
     _SMP_DEFAULTS = {'encoder_depth': 5, 'decoder_use_batchnorm': True, 'decoder_channels': (256, 128, 64, 32, 16),
-                     'decoder_attention_type': None, 'activation': None, 'aux_params': None}
+                     'decoder_attention_type': None, 'activation': None, 'aux_params': None,
+                     # smp.FPN's own keywords, at their defaults
+                     'decoder_pyramid_channels': 256, 'decoder_segmentation_channels': 128, 'decoder_merge_policy': 'add',
+                     'decoder_dropout': 0.2, 'upsampling': 4}
 
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
                  device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
         super().__init__()
         use_graph = bool(kwargs.pop('use_graph', False))   # eval forwards as replayed hipGraphs (serving)
+        use_train_graph = bool(kwargs.pop('use_train_graph', False))
         for k, v in kwargs.items():
             if k not in self._SMP_DEFAULTS:
                 raise TypeError(f'SegNet got an unexpected keyword argument {k!r}')
@@ -178,6 +183,12 @@ class SegNet(nn.Module):
         self.device = torch.device(device)
         self._plans = {}
         self.use_graph = use_graph
+        # train_step_raw as ONE replayed hipGraph per (B, H, W) plan (octseg_net_train_step + octseg_plan_set_train_graph): the ~800
+        # launches of a step cost the host tens of milliseconds to enqueue, which bounds small per-GPU batches; not with `exchange`
+        self.use_train_graph = use_train_graph
+        # arch 'fpn': nn.Dropout2d(0.2) sits behind the merge.  Training forwards draw a keep pattern [B, 128] on the device (torch's
+        # RNG, as the reference's Dropout2d does) unless `dropout_keep` holds one (tests inject the oracle's); eval ignores it.
+        self.dropout_keep = None
         self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
         self._buffer_epoch = 0  # the same for bn_buffers (every train-mode forward)
         # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
@@ -373,6 +384,54 @@ class SegNet(nn.Module):
             raise ValueError(f'expected a float32 CUDA tensor [B,3,H,W], got {tuple(x.shape)} {x.dtype} {x.device}')
         return x.contiguous()
 
+    def _graph_train_step(self, image, target, normalize, mean, std, grad_scale):
+        """forward + Dice + backward through octseg_net_train_step with the plan's training graph on: inputs are copied into persistent
+        buffers (a replay needs every pointer unchanged), the step runs on a capturable stream, outputs come back as copies."""
+        x = self._check_input(image)
+        B, _, H, W = x.shape
+        plan = self._plan(B, H, W)
+        plan.generation += 1
+        ver = (self.arena._version, self._param_epoch)
+        if getattr(plan, 'seen_version', None) != ver:
+            L.check(L.lib().octseg_plan_params_changed(plan.handle))
+            plan.seen_version = ver
+        target = target.contiguous()
+        if tuple(target.shape) != (B, self.classes, H, W) or target.dtype != torch.float32:
+            raise ValueError(f'mask must be float32 {(B, self.classes, H, W)}, got {target.dtype} {tuple(target.shape)}')
+        io = getattr(plan, 'train_io', None)
+        if io is None:
+            dev = x.device
+            io = plan.train_io = dict(
+                img=torch.empty_like(x), mask=torch.empty_like(target),
+                logits=torch.empty((B, self.classes, H, W), dtype=torch.float32, device=dev),
+                loss=torch.empty((), dtype=torch.float32, device=dev),
+                stats=torch.empty((B, self.classes, 4), dtype=torch.int64, device=dev),
+                keep=torch.ones((B, _FPN_SEG_CHANNELS), dtype=torch.float32, device=dev),
+                stream=torch.cuda.Stream(device=dev))    # (the legacy default stream cannot be captured)
+            L.check(L.lib().octseg_plan_set_train_graph(plan.handle, 1))
+            if self.arch == 'fpn':
+                L.check(L.lib().octseg_plan_set_dropout(plan.handle, L.ptr(io['keep'])))
+        io['img'].copy_(x)
+        io['mask'].copy_(target)
+        if self.arch == 'fpn':
+            keep = self.dropout_keep
+            if keep is None:
+                keep = torch.bernoulli(torch.full((B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT, device=x.device))
+            io['keep'].copy_(keep.to(x.device, torch.float32))
+        m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
+        s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
+        cur = torch.cuda.current_stream(x.device)
+        io['stream'].wait_stream(cur)
+        with torch.cuda.stream(io['stream']):
+            L.check(L.lib().octseg_net_train_step(plan.handle, L.ptr(self.arena.data), L.ptr(self._grad_arena), L.ptr(self.bn_buffers),
+                                                  L.ptr(plan.ws(x.device)), L.ptr(io['img']), L.ptr(io['mask']), L.ptr(io['logits']),
+                                                  L.ptr(io['loss']), L.ptr(io['stats']), int(bool(normalize)), m, s, float(grad_scale),
+                                                  L.stream_ptr()))
+        cur.wait_stream(io['stream'])
+        self.num_batches_tracked += 1
+        self._buffer_epoch += 1
+        return io['loss'].clone(), io['logits'].clone(), io['stats'].clone()
+
     def _run_forward(self, x, normalize, mean, std, train):
         x = self._check_input(x)
         B, _, H, W = x.shape
@@ -389,6 +448,15 @@ class SegNet(nn.Module):
             plan.seen_version = ver
         if not train:
             plan.seen_buffers = bver
+        if self.arch == 'fpn' and train:
+            keep = self.dropout_keep
+            if keep is None:
+                keep = torch.bernoulli(torch.full((B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT, device=x.device))
+            keep = keep.to(x.device, torch.float32).contiguous()
+            if tuple(keep.shape) != (B, _FPN_SEG_CHANNELS):
+                raise ValueError(f'dropout_keep must be [{B}, {_FPN_SEG_CHANNELS}] of 0 / 1, got {tuple(keep.shape)}')
+            plan.drop_keep = keep      # the backward of this step reads it too: keep it alive with the plan
+            L.check(L.lib().octseg_plan_set_dropout(plan.handle, L.ptr(keep)))
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
         want_graph = bool(self.use_graph and not train)
@@ -465,6 +533,10 @@ class SegNet(nn.Module):
         exposed as ``arena.grad`` without a copy).  The bench / DP loop uses this.  ``exchange``: a
         ``parallel.GradientExchange`` -- the backward then hands the gradient arena out slice by slice and the
         all-reduce of each slice overlaps the rest of the backward; on return the gradients are the cross-rank sums."""
+        if self.use_train_graph and exchange is None and self.training:
+            loss, logits, stats = self._graph_train_step(image, target, normalize, mean, std, grad_scale)
+            self.arena.grad = self._grad_arena
+            return loss, logits, stats
         logits, loss, stats, plan = self._forward_loss(image, target, normalize, mean, std)
         if exchange is not None:
             exchange.backward(plan, logits, target, grad_scale, generation=plan.generation)

@@ -331,3 +331,40 @@ def test_reference_attribute_paths(cuda):
         last.register_forward_hook(lambda *a: None)
     with pytest.raises(AttributeError):
         m.model.encoder.layer5
+
+
+@pytest.mark.parametrize('arch,enc,dtype', [('unetplusplus', 'resnet18', torch.float32), ('linknet', 'resnet50', torch.bfloat16), ('fpn', 'resnet18', torch.float32)])
+def test_captured_training_step_equals_eager_bit_for_bit(cuda, arch, enc, dtype):
+    """octseg_net_train_step under octseg_plan_set_train_graph: warm-up call, capture, replay -- the replayed hipGraph (weight packing,
+    forward lanes, the weight-gradient side stream and every event edge inside) must leave loss, logits, confusion counts, BatchNorm
+    running statistics and the whole gradient arena bit-identical to the eager launches (deterministic reductions on both sides), and a
+    second replay on NEW parameters must follow them (reference: training_step + loss.backward(), model.py:73-95, every step)."""
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.engine import SegNet
+    classes = 2
+    img, mask = (t.to(cuda) for t in make_batch(2, classes, 64, seed=31))
+    img2, mask2 = (t.to(cuda) for t in make_batch(2, classes, 64, seed=32))
+    keep = (torch.rand(2, 128, generator=torch.Generator().manual_seed(4)) < 0.8).float()
+    L.check(L.lib().octseg_set_deterministic(1))
+    try:
+        def run(graph):
+            net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=dtype, seed=11).train()
+            net.use_train_graph = graph
+            net.dropout_keep = keep
+            out = []
+            for k, (im, mk) in enumerate(((img, mask), (img, mask), (img2, mask2), (img, mask))):
+                if k == 3:                              # parameters changed in place between replays: the graph repacks the weight images
+                    with torch.no_grad():
+                        net.arena.data.mul_(1.01)
+                    net.params_changed()
+                loss, logits, stats = net.train_step_raw(im, mk, normalize=True, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], grad_scale=0.5)
+                torch.cuda.synchronize()
+                out.append((loss.clone(), logits.clone(), stats.clone(), net.arena.grad.clone(), net.bn_buffers.clone()))
+            return out
+        eager, graph = run(False), run(True)
+    finally:
+        L.check(L.lib().octseg_set_deterministic(0))
+    for k, (a, b) in enumerate(zip(eager, graph)):       # k = 0 eager warm-up, 1 capture + first launch, 2 and 3 replays
+        for name, x, y in zip(('loss', 'logits', 'stats', 'grads', 'bn_buffers'), a, b):
+            assert torch.equal(x, y), f'step {k}: {name} differs between the captured and the eager step'
+    assert not torch.equal(eager[1][3], eager[2][3]) and not torch.equal(eager[1][3], eager[3][3])

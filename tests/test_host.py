@@ -76,8 +76,11 @@ def test_plan_argument_validation():
     lib = L.lib()
     rc, _ = _plan('unet', 'resnet18', 1, 1, 100, 100)
     assert rc == -1 and b'divisible by 32' in lib.octseg_last_error()   # smp check_input_shape text
-    rc, _ = _plan('fpn', 'resnet18', 1, 1, 64, 64)
+    rc, _ = _plan('pspnet', 'resnet18', 1, 1, 64, 64)      # (an smp architecture outside the built set)
     assert rc == -3
+    rc, pf = _plan('fpn', 'resnet18', 1, 1, 64, 64)         # FPN is built since round 3
+    assert rc == 0
+    lib.octseg_plan_destroy(pf)
     rc, _ = _plan('unet', 'vgg16', 1, 1, 64, 64)
     assert rc == -3
     rc, _ = _plan('unet', 'resnet18', 1, 1, 64, 64, dt=7)
@@ -205,7 +208,7 @@ def test_metrics_csv_bookkeeping(tmp_path):
 def test_planner_and_executors_clean_under_asan_ubsan():
     """SURVEY section 5 (sanitizers): the host halves of every source -- csrc/plan.cpp's graph builder, workspace layout, tap tables, launch
     geometry, job tables, and the forward / backward / sliced-backward / optimizer / graph executors -- compiled with
-    -fsanitize=address,undefined and driven over all 15 arch x encoder pairs (32x32, 16 x 704x704, 96x64, 64x160; f32 / bf16 / f16)
+    -fsanitize=address,undefined and driven over all 20 arch x encoder pairs (U-Net, U-Net++, LinkNet, FPN) (32x32, 16 x 704x704, 96x64, 64x160; f32 / bf16 / f16)
     against a recording stand-in for the HIP runtime (tools/hip_host_stubs.cpp: every launch geometry and every memset / copy range is
     checked; nothing runs on a GPU).  `make asan` builds build/asan/plan_dryrun; exit code 0 and the summary line = clean."""
     import subprocess
@@ -216,4 +219,4 @@ def test_planner_and_executors_clean_under_asan_ubsan():
     r = subprocess.run([os.path.join(csrc, 'build', 'asan', 'plan_dryrun')], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-6000:]
-    assert '270 plans built' in r.stdout and '0 errors' in r.stdout, r.stdout
+    assert '360 plans built' in r.stdout and '0 errors' in r.stdout, r.stdout
