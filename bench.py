@@ -293,6 +293,7 @@ def main():
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)')
+    ap.add_argument('--profile-timed', action='store_true', help='also bracket every launch of the timed steps with HIP events (roofline.overlapped)')
     ap.add_argument('--train-graph', action='store_true',
                     help='forward + Dice + backward of a step as one replayed hipGraph (octseg_net_train_step); N = 1 or without the exchange')
     ap.add_argument('--force-exchange', action='store_true',
@@ -390,7 +391,9 @@ def main():
         step()
     barrier()
     note(f'timing {args.steps} steps')
-    L.check(L.lib().octseg_profile_start())
+    # HIP-event brackets around every launch of the TIMED steps cost the host two event records per launch (~800 per step): opt-in
+    if args.profile_timed:
+        L.check(L.lib().octseg_profile_start())
     sampler = PowerSampler(dev) if rank == 0 else None
     if sampler is not None:
         sampler.start()
@@ -404,7 +407,8 @@ def main():
     dt = time.perf_counter() - t0
     power = sampler.stop() if sampler is not None else None
     prof = (C.c_double * 12)()
-    L.check(L.lib().octseg_profile_stop(prof))
+    if args.profile_timed:
+        L.check(L.lib().octseg_profile_stop(prof))
     loss_val = float(loss.item())
     # Roofline pass (untimed, after the measured steps): the same step with every launch on one stream, so that the
     # HIP-event bracket of a launch is the duration of that kernel alone.  In the timed steps the weight gradients and
@@ -467,7 +471,7 @@ def main():
                 'note': 'HIP-event brackets on the launch stream over an untimed pass of the same step with every launch on one '
                         'stream (octseg_debug_set_serial): the duration of each kernel alone; rocprofv3 summary of that mode: '
                         'profiles/r2_serial_kernel_stats.csv',
-                'overlapped': {
+                'overlapped': None if not args.profile_timed else {
                     'note': 'the same brackets during the TIMED steps, where weight gradients and part of the decoder run on a '
                             'side stream: durations include the time a kernel shares the chip (profiles/r2_bench_kernel_stats.csv)',
                     'kernel_ms_per_step': round(sum(oms) / args.steps, 3),
