@@ -1231,6 +1231,18 @@ static Choice choose(const ConvArgs& a, int esz) {
   }
   int NT, WN;
   if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
+  // Small grids (small per-GPU batches -- strong scaling -- and the deepest stages): a multi-tap layer whose 16x16-pixel x 128-channel
+  // tiles number fewer than half the CUs runs at the speed of ONE workgroup's loop (U-Net++/resnet101 at 2 frames per GPU: x_0_0.conv1,
+  // 3072 -> 256 @44^2, is 36 workgroups of 27648-deep contractions: 166 TFLOP/s).  A 64-channel N tile and the 8x16-pixel M tile
+  // quadruple the workgroup count at the price of slab reuse, which an under-filled chip does not miss.
+  bool small_grid = false;
+  {
+    static const bool off = getenv("OCTSEG_NO_SMALLGRID") != nullptr;   // A/B switch
+    const int bn = NT * 32 * WN;
+    const long long w16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) * ((a.Cout + bn - 1) / bn);
+    small_grid = !off && a.ntaps > 1 && w16 < 128;
+    if (small_grid && a.Cout > 64) { NT = 1; WN = 2; }
+  }
   const int kc128 = 128 / esz;
   const int RB = a.Cin <= kc128 / 2 ? 64 : 128;
   auto util = [&](int TH) {
@@ -1262,6 +1274,7 @@ static Choice choose(const ConvArgs& a, int esz) {
       // (tried in round 2: 8x16 tiles for the 1.1-round case of ResNet layer3, 288 -> 576 workgroups: 87 -> 93 us per layer, not kept)
     }
   }
+  if (small_grid) wm_first = 2;
   static const int force_wm = getenv("OCTSEG_FORCE_WM") ? atoi(getenv("OCTSEG_FORCE_WM")) : 0;   // A/B switch
   if (force_wm) wm_first = force_wm;
   const int order[2] = {wm_first, wm_first == 4 ? 2 : 4};

@@ -649,6 +649,8 @@ static int build_plan(octseg_plan* P) {
   P->slab_off = off; P->slab_bytes = align_up(slab); off += 2 * align_up(slab);          // one slab per forward lane
   P->fin_part_off = off; off += 2 * align_up(4096 * 2 * sizeof(double));   // two-level slab reduction scratch (per lane)
   P->fin_cnt_off = off; off += align_up(2 * 64 * sizeof(unsigned));
+  P->bwd_part_off = off; off += align_up((size_t)8 * 32 * 4096 * sizeof(double));   // [column][group][256 vectors x 8 channels x 2]
+  P->bwd_cnt_off = off; off += align_up((size_t)8 * 33 * 32 * sizeof(unsigned));   // one 128-byte line per ticket
   {
     size_t pool_elems = 0;
     for (auto& op : P->ops)
@@ -960,13 +962,15 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   a.coef = E.bn_coef(bn);
   a.dy = E.grad(b.y);
   a.res_grad = res_grad; a.res_store = res_store;
+  const bool fused_fin = bn_bwd_fused_finalize();   // the reduce kernel finishes the reduction itself: no finalize launch
+  if (fused_fin) { a.fpart = (double*)(E.ws + P->bwd_part_off); a.fcnt = (unsigned*)(E.ws + P->bwd_cnt_off); }
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
   {
     ProfScope ps(3, tbytes * (mask == 2 ? 3 : 2), E.st, b.name + ".bwd_reduce");
     HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
   }
-  HIPCHK(launch_bn_bwd_finalize(a, E.st));
+  if (!fused_fin) HIPCHK(launch_bn_bwd_finalize(a, E.st));
   {
     ProfScope ps(3, tbytes * ((mask == 2 ? 4 : 3) + (res_grad ? (res_store ? 1 : 2) : 0)), E.st, b.name + ".bwd_apply");
     HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
@@ -1122,6 +1126,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   };
   HIPCHK(hipMemsetAsync(E.grads, 0, P->param_numel * sizeof(float), E.st));
   HIPCHK(hipMemsetAsync(E.ws + P->fin_cnt_off, 0, 2 * 64 * sizeof(unsigned), E.st));
+  HIPCHK(hipMemsetAsync(E.ws + P->bwd_cnt_off, 0, 8 * 33 * 32 * sizeof(unsigned), E.st));
   E.ginit.assign(P->tensors.size(), 0);
   static const bool no_side = getenv("OCTSEG_NO_SIDE_STREAM") != nullptr;   // A/B switch
   if (!no_side && !serial_mode()) {

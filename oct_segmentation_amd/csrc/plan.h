@@ -109,6 +109,7 @@ struct octseg_plan {
   size_t slab_off = 0, slab_bytes = 0;       // BN partial-sum slab (reused per layer; one per forward lane)
   bool has_lanes = false;
   size_t fin_part_off = 0, fin_cnt_off = 0;  // scratch of the two-level slab reduction (BN finalize)
+  size_t bwd_part_off = 0, bwd_cnt_off = 0;  // scratch / tickets of the BN-backward reduce kernel that finishes its own reduction
   size_t pool_idx_off = 0;                   // maxpool: window position of every maximum (1 byte per output element)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
