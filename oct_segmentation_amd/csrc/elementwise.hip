@@ -184,6 +184,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) x[i] += pp[i];
     }
+    if (a.maskbits != nullptr) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) bits |= (x[i] > 0.f ? 1u : 0u) << i;
+      a.maskbits[v] = (unsigned char)bits;
+    }
     stv<T>(a.out, v, EV<T>::pack(x));
   }
 }
@@ -237,10 +243,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     EV<T>::unpack(ldv<T>(a.g, v), g);
     EV<T>::unpack(ldv<T>(a.y, v), y);
     if (a.mask == 2) {
-      float o[VEC];
-      EV<T>::unpack(ldv<T>(a.out, v), o);
+      if (a.maskbits != nullptr) {
+        const unsigned bits = a.maskbits[v];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
+        for (int i = 0; i < VEC; ++i) if (!((bits >> i) & 1u)) g[i] = 0.f;
+      } else {
+        float o[VEC];
+        EV<T>::unpack(ldv<T>(a.out, v), o);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
+      }
     } else if (a.mask == 1) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], sc[i], sh[i]) > 0.f)) g[i] = 0.f;
@@ -384,11 +396,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   constexpr int U = 4;
   for (size_t vb = v0; vb < nvec; vb += U * stride) {
     uint4 gv[U], yv[U], ov[U];
+    unsigned mb[U];
+    const bool use_bits = a.mask == 2 && a.maskbits != nullptr;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t v = vb + u * stride < nvec ? vb + u * stride : vb;
       gv[u] = ldv<T>(a.g, v); yv[u] = ldv<T>(a.y, v);
-      if (a.mask == 2) ov[u] = ldv<T>(a.out, v);
+      mb[u] = 0;
+      if (use_bits) mb[u] = a.maskbits[v];
+      else if (a.mask == 2) ov[u] = ldv<T>(a.out, v);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -397,7 +413,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       float g[VEC], y[VEC];
       EV<T>::unpack(gv[u], g);
       EV<T>::unpack(yv[u], y);
-      if (a.mask == 2) {
+      if (use_bits) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) if (!((mb[u] >> i) & 1u)) g[i] = 0.f;
+      } else if (a.mask == 2) {
         float o[VEC];
         EV<T>::unpack(ov[u], o);
 #pragma unroll

@@ -69,6 +69,8 @@ struct BnActArgs {
   const void* res; const float* rscale; const float* rshift;  // pre-activation residual (nullable)
   const void* post;                                           // post-activation addend (nullable)
   void* out; size_t npix; int C; int relu;
+  unsigned char* maskbits;   // nullable (training forwards): one byte per 16-byte vector, bit i = (output element i > 0): the ReLU mask the
+                             // BatchNorm backward would otherwise re-read the whole output tensor for, twice
 };
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st);
 
@@ -76,6 +78,7 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st);
 // 2 out > 0 (materialised tensor `out`).  Pass 1 writes [rows][C][2] partials (sum dz, sum dz*xhat).
 struct BnBwdArgs {
   const void* g; const void* y; const void* out;  // out: mask source for mode 2
+  const unsigned char* maskbits;                  // mode 2: the forward's saved mask bits (BnActArgs::maskbits) instead of `out` when not null
   const float* scale; const float* shift; const float* mean; const float* rstd; const float* gamma;
   size_t npix; int C; int mask;
   float* slab; int rows;                 // pass 1 output

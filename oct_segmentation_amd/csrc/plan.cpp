@@ -559,6 +559,15 @@ static int build_plan(octseg_plan* P) {
   for (auto& t : P->tensors)
     if (t.need_grad && t.grad_alias >= 0) t.goff = P->tensors[t.grad_alias].goff;
   P->grad_end = off;
+  {
+    static const bool no_bits = getenv("OCTSEG_NO_MASKBITS") != nullptr;   // A/B switch: the backward re-reads the output tensor for the mask
+    for (auto& op : P->ops)
+      if (!no_bits && op.kind == OP_BN_ACT && op.relu && op.post < 0) {
+        TensorInfo& t = P->tensors[op.out];
+        const size_t nvec = (size_t)t.N * t.H * t.W * t.C * esz / 16;
+        t.mask_off = off; off += align_up(nvec);
+      }
+  }
   for (auto& g : P->gns) {
     const TensorInfo& t = P->tensors[g.y];
     const size_t S = (size_t)gn_num_slabs((size_t)t.H * t.W);
@@ -886,6 +895,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         }
         if (op.post >= 0) a.post = E.act(op.post);
         a.out = E.act(op.out); a.npix = (size_t)t.N * t.H * t.W; a.C = t.C; a.relu = op.relu;
+        if (E.train && t.mask_off) a.maskbits = (unsigned char*)(E.ws + t.mask_off);
         {
           const double tb = (double)a.npix * a.C * dtype_size(P->dtype);
           ProfScope ps(3, tb * (2 + (a.res ? 1 : 0) + (a.post ? 1 : 0)), st, "bn_act");
@@ -939,13 +949,14 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
 }
 
 // BN backward of BN `bn` over raw tensor y: g -> dy (written to grad(y))
-static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out_mask, void* res_grad = nullptr, int res_store = 0) {
+static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out_mask, void* res_grad = nullptr, int res_store = 0,
+                       const unsigned char* maskbits = nullptr) {
   octseg_plan* P = E.P;
   const BNInfo& b = P->bns[bn];
   const TensorInfo& t = P->tensors[b.y];
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = g; a.y = E.act(b.y); a.out = out_mask;
+  a.g = g; a.y = E.act(b.y); a.out = out_mask; a.maskbits = maskbits;
   a.scale = E.bn_scale(bn); a.shift = E.bn_shift(bn); a.mean = E.bn_mean(bn); a.rstd = E.bn_rstd(bn);
   a.gamma = E.params + P->params[b.gamma].off;
   a.npix = (size_t)t.N * t.H * t.W; a.C = b.C; a.mask = mask;
@@ -967,12 +978,12 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
   {
-    ProfScope ps(3, tbytes * (mask == 2 ? 3 : 2), E.st, b.name + ".bwd_reduce");
+    ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 3 : 2), E.st, b.name + ".bwd_reduce");
     HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
   }
   if (!fused_fin) HIPCHK(launch_bn_bwd_finalize(a, E.st));
   {
-    ProfScope ps(3, tbytes * ((mask == 2 ? 4 : 3) + (res_grad ? (res_store ? 1 : 2) : 0)), E.st, b.name + ".bwd_apply");
+    ProfScope ps(3, tbytes * (((mask == 2 && !maskbits) ? 4 : 3) + (res_grad ? (res_store ? 1 : 2) : 0)), E.st, b.name + ".bwd_apply");
     HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
   }
   return OCTSEG_OK;
@@ -1177,16 +1188,17 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         static const bool no_fuse_res = getenv("OCTSEG_NO_FUSED_RESGRAD") != nullptr;   // A/B switch
         const bool fuse_res = !no_fuse_res && mask == 2 && op.res.t >= 0 && op.res.bn < 0 && P->tensors[op.res.t].need_grad &&
                               E.grad(op.res.t) != G && E.grad(op.res.t) != E.grad(P->bns[op.y.bn].y);
+        const unsigned char* mbits = (mask == 2 && t.mask_off) ? (const unsigned char*)(E.ws + t.mask_off) : nullptr;
         if (fuse_res) {
           const int acc = E.claim(op.res.t);
-          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out), E.grad(op.res.t), acc ? 0 : 1);
+          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out), E.grad(op.res.t), acc ? 0 : 1, mbits);
         } else {
-          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out));
+          rc = bn_backward(E, op.y.bn, G, mask, E.act(op.out), nullptr, 0, mbits);
         }
         if (rc) return rc;
         if (op.res.t >= 0 && !fuse_res) {
           if (op.res.bn >= 0) {
-            rc = bn_backward(E, op.res.bn, G, op.relu ? 2 : 0, E.act(op.out));
+            rc = bn_backward(E, op.res.bn, G, op.relu ? 2 : 0, E.act(op.out), nullptr, 0, (op.relu && t.mask_off) ? (const unsigned char*)(E.ws + t.mask_off) : nullptr);
             if (rc) return rc;
           } else if (P->tensors[op.res.t].need_grad) {
             const int acc = E.claim(op.res.t);

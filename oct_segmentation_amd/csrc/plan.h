@@ -14,6 +14,7 @@ struct TensorInfo {
   size_t goff;   // byte offset of its gradient buffer (valid when need_grad)
   bool need_grad;
   bool external; // logits / image: not in the workspace
+  size_t mask_off = 0;  // bn_act outputs whose ReLU mask the backward needs: byte offset of their mask bits (1 byte per 16-byte vector), else 0
   int grad_alias = -1;  // >= 0: shares the gradient buffer of that tensor (the summands of a merge-add all receive the same gradient)
 };
 
