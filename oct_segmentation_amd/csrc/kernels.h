@@ -41,6 +41,21 @@ int thin_conv_rows(const ConvArgs& a);
 hipError_t launch_thin_conv(int dtype, const ConvArgs& a, hipStream_t st);
 bool thin_wgrad_eligible(const WgradArgs& a, int dtype);
 hipError_t launch_thin_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+// ... and the ResNet stem (7x7 stride 2, 3 -> 64) straight from the NCHW f32 frame: forward (+ BN partials, one slab row per workgroup =
+// thin_stem_rows) and weight gradient; no im2col tensor
+struct StemArgs {
+  const float* img; int N, H, W;            // frame [N][3][H][W] f32
+  int normalize; float mean[3], stdv[3];
+  const float* w;                            // fp32 master [64][160], k = (r * 7 + s) * 3 + ci
+  const float* wscale; const float* bias; int relu_out;   // eval: folded BatchNorm
+  void* y;                                   // forward: raw output NHWC T [N][H/2][W/2][64]
+  float* slab; int slab_row0;
+  const void* dy; float* dW;                 // weight gradient: dy NHWC T [N][H/2][W/2][64], dW [64][160] accumulated
+};
+bool thin_stem_eligible(int dtype);
+int thin_stem_rows(int N, int H, int W);
+hipError_t launch_thin_stem_forward(int dtype, const StemArgs& s, hipStream_t st);
+hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);

@@ -602,7 +602,10 @@ static int build_plan(octseg_plan* P) {
       L.pk_dgrad = conv_pack_info(d0, P->dtype);
       L.wimg_dgrad_off = off; off += align_up(conv_image_bytes(L.pk_dgrad, wtaps));
     }
-    if (L.bn >= 0) {
+    if (L.bn >= 0 && L.stem && thin_stem_eligible(P->dtype)) {
+      P->bns[L.bn].rows = thin_stem_rows(L.N, P->H, P->W);   // the stem runs in thin.hip straight from the frame: one slab row per workgroup
+      slab = std::max(slab, (size_t)P->bns[L.bn].rows * L.Cout * 2 * sizeof(float));
+    } else if (L.bn >= 0) {
       int rows = 0;
       for (auto& a : la) {
         // geometry-only descriptors, so that the tile count equals what run_forward will launch
@@ -827,13 +830,35 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
     switch (op.kind) {
       case OP_STEM_COL: {
         const TensorInfo& t = P->tensors[op.out];
-        HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st));
+        // (2-byte dtypes: the stem conv gathers its im2col rows straight from the frame in LDS, thin.hip KSTEM -- no 634 MB tensor)
+        if (!thin_stem_eligible(P->dtype))
+          HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st));
         tseq[op.out] = stamp;
         break;
       }
       case OP_CONV: {
         const ConvLayer& L = P->convs[op.conv];
         for (auto& sct : L.srcs) { rc = need_val(lane, sct.v); if (rc) return rc; }
+        if (L.stem && thin_stem_eligible(P->dtype)) {
+          StemArgs sa;
+          memset(&sa, 0, sizeof(sa));
+          sa.img = image; sa.N = P->B; sa.H = P->H; sa.W = P->W; sa.normalize = normalize;
+          for (int i = 0; i < 3; ++i) { sa.mean[i] = normalize ? mean[i] : 0.f; sa.stdv[i] = normalize ? stdv[i] : 1.f; }
+          sa.w = E.params + P->params[L.w].off;
+          if (folded && L.bn >= 0) { sa.wscale = E.bn_scale(L.bn); sa.bias = E.bn_shift(L.bn); sa.relu_out = P->bns[L.bn].lazy ? 1 : 0; }
+          sa.y = E.act(L.out);
+          sa.slab = (L.bn >= 0 && E.train) ? slab_l : nullptr; sa.slab_row0 = 0;
+          {
+            ProfScope ps(0, 2.0 * layer_macs(L), st, L.name);
+            HIPCHK(launch_thin_stem_forward(P->dtype, sa, st));
+          }
+          if (E.train) {   // the weight gradient re-gathers the frame: remember where it is (the caller keeps it alive until the backward)
+            P->stem_image = image; P->stem_normalize = normalize;
+            for (int i = 0; i < 3; ++i) { P->stem_mean[i] = sa.mean[i]; P->stem_std[i] = sa.stdv[i]; }
+          }
+          tseq[L.out] = stamp;
+          break;
+        }
         std::vector<ConvArgs> la;
         fwd_launches(E.geom(L), la);
         int row0 = 0;
@@ -841,7 +866,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.nsrc = E.fill_srcs(L, a.src);
           a.W = fwd_weight(E, L);
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
-          if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0; }
+          if (!L.stem) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0; }   // (ConvT: [4][4][O][I], same indexing)
           if (folded) {
             for (int i = 0; i < a.nsrc; ++i) { a.src[i].scale = nullptr; a.src[i].shift = nullptr; a.src[i].relu = 0; }
             if (L.bn >= 0) { a.bias = E.bn_shift(L.bn); a.relu_out = P->bns[L.bn].lazy ? 1 : 0; a.wscale = E.bn_scale(L.bn); }
@@ -993,6 +1018,29 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   octseg_plan* P = E.P;
   const size_t esz = dtype_size(P->dtype);
   const Geom g = E.geom(L);
+  if (L.stem && thin_stem_eligible(P->dtype)) {
+    // the forward built no im2col tensor.  Weight gradient straight from the frame (thin.hip); the deterministic-reduction mode keeps the
+    // atomics-free kernel and rebuilds the im2col rows for it here.  The frame needs no gradient.
+    if (P->stem_image == nullptr) return fail(OCTSEG_BAD_ARG, "backward without a training forward of this plan (stem frame unknown)");
+    hipStream_t ws_ = E.wst ? E.wst : E.st;
+    if (ws_ != E.st) {
+      HIPCHK(hipEventRecord(P->ev_fork, E.st));
+      HIPCHK(hipStreamWaitEvent(ws_, P->ev_fork, 0));
+    }
+    if (P->dtype == DT_BF16 && !deterministic_mode()) {
+      StemArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.img = P->stem_image; sa.N = P->B; sa.H = P->H; sa.W = P->W; sa.normalize = P->stem_normalize;
+      for (int i = 0; i < 3; ++i) { sa.mean[i] = P->stem_mean[i]; sa.stdv[i] = P->stem_std[i]; }
+      sa.dy = dy; sa.dW = E.grads + P->params[L.w].off;
+      ProfScope ps(2, 2.0 * layer_macs(L), ws_, L.name);
+      HIPCHK(launch_thin_stem_wgrad(P->dtype, sa, ws_));
+      return OCTSEG_OK;
+    }
+    const TensorInfo& tc = P->tensors[P->col_tensor];
+    HIPCHK(launch_stem_im2col(P->dtype, P->stem_image, E.act(P->col_tensor), P->B, P->H, P->W, tc.C, P->stem_mean, P->stem_std,
+                              P->stem_normalize, ws_));
+  }
   // bias gradient
   if (L.b >= 0)
     HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, E.st));

@@ -102,6 +102,8 @@ struct octseg_plan {
   // FPN: the head runs at stride 4 into z4 (NCHW f32) and is resampled x4 into the logits; its gradient comes back through dz4
   int head_up = 1;
   size_t z4_off = 0, dz4_off = 0;
+  // stem through thin.hip: frame and normalisation of the last training forward (its weight gradient gathers the frame again)
+  const float* stem_image = nullptr; int stem_normalize = 0; float stem_mean[3] = {0, 0, 0}, stem_std[3] = {1, 1, 1};
   const float* dropout_keep = nullptr;   // device [B][128] of {0, 1}: Dropout2d keep pattern of the next training forward (caller-owned)
   float dropout_p = 0.2f;
   size_t param_numel = 0, buffer_numel = 0;

@@ -77,6 +77,7 @@ class _DiceStep(torch.autograd.Function):
     def forward(ctx, arena, net, image, target, normalize, mean, std):
         logits, loss, stats, plan = net._forward_loss(image, target, normalize, mean, std)
         ctx.net, ctx.plan, ctx.logits, ctx.target, ctx.generation = net, plan, logits, target, plan.generation
+        ctx.image = image   # the stem's weight gradient gathers the frame again in the backward: keep it alive
         ctx.mark_non_differentiable(logits, stats)
         return loss, logits, stats
 

@@ -46,6 +46,12 @@ CASES = [
     (1, 80, 72, 16, 32, 3, 1, 1, False),
     (3, 40, 104, 32, 32, 3, 1, 1, False),    # x_0_3.conv2 shape: two output blocks both ways
     (5, 112, 96, 16, 16, 3, 1, 1, False),    # 1050 tiles > 768 workgroups: some walk two tiles
+    # thin 1x1 layers (LinkNet's last decoder block / head shapes) and the parity launches of a thin ConvTranspose2d forward
+    (2, 64, 96, 16, 32, 1, 1, 0, False),     # forward 16 -> 32 (two output blocks), dgrad 32 -> 16, wgrad with a 32-channel dy
+    (2, 64, 104, 32, 16, 1, 1, 0, False),
+    (3, 40, 72, 32, 32, 1, 1, 0, False),
+    (2, 48, 64, 16, 16, 4, 2, 1, True),      # ConvTranspose2d 16 -> 16: four 2x2-tap launches writing at stride 2
+    (1, 64, 80, 32, 32, 4, 2, 1, True),
 ]
 
 
