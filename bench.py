@@ -28,7 +28,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before HIP initialises: see oct_segmentation_amd/_lib.py (side stream vs RCCL's streams)
+if int(os.environ.get('WORLD_SIZE', '1') or 1) > 1 or '--force-exchange' in sys.argv:   # before HIP initialises: see oct_segmentation_amd/_lib.py
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')                                       # (side stream vs RCCL's streams; costs graph replay)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
@@ -460,7 +461,7 @@ def main():
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3),
             'power': power,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + gemm1x1_kernel + wgrad_mfma_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + conv3x3p_kernel + gemm1x1_kernel + thin_conv_kernel + wgrad_mfma_kernel + thin_wgrad_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
@@ -470,10 +471,10 @@ def main():
                 'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
                 'note': 'HIP-event brackets on the launch stream over an untimed pass of the same step with every launch on one '
                         'stream (octseg_debug_set_serial): the duration of each kernel alone; rocprofv3 summary of that mode: '
-                        'profiles/r2_serial_kernel_stats.csv',
+                        'profiles/r3_serial_kernel_stats.csv',
                 'overlapped': None if not args.profile_timed else {
                     'note': 'the same brackets during the TIMED steps, where weight gradients and part of the decoder run on a '
-                            'side stream: durations include the time a kernel shares the chip (profiles/r2_bench_kernel_stats.csv)',
+                            'side stream: durations include the time a kernel shares the chip (profiles/r3_bench_kernel_stats.csv)',
                     'kernel_ms_per_step': round(sum(oms) / args.steps, 3),
                     'achieved': round(sum(ofl) / (sum(oms) * 1e-3) / 1e12, 2) if sum(oms) > 0 else 0.0,
                     'by_class': {k: {'ms_per_step': round(m / args.steps, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}

@@ -9,9 +9,17 @@ import os
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  The engine overlaps the weight gradients (side
 # stream) and a forward lane with the caller's stream; once RCCL has created its own streams (init_process_group("nccl")) the side
 # stream can land on the SAME hardware queue as the main one and the overlap is silently gone: measured on one MI355X, U-Net++/resnet101
-# B=16, 76.3 -> 83.6 ms per step with a one-rank RCCL group and nothing else changed, back to 76.5 with 8 queues.  Must be in the
-# environment before the HIP runtime initialises (first torch.cuda call); an explicit setting of the user wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# B=16, 74.2 -> 80.8 ms per step with a one-rank RCCL group and nothing else changed, 74.6 with 8 (or 2) queues.  The setting is NOT
+# free for hipGraph replay, though: with 8 queues the replayed serving ensemble runs at 15.7 ms per frame instead of 7.0 and a replayed
+# training step at 98.5 ms instead of 79.2 (profiles/r3_hw_queues_ab.txt), and with 2 graph instantiation fails.  So it is applied to
+# the processes that open a process group -- the ranks of a torchrun launch (WORLD_SIZE > 1); single-GPU processes keep HIP's
+# default.  Must be in the environment before the HIP runtime initialises (first torch.cuda call); an explicit setting of the user wins.
+def set_hw_queues_for_collectives():
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
+if int(os.environ.get('WORLD_SIZE', '1') or 1) > 1:
+    set_hw_queues_for_collectives()
 
 # torch bundles its own libamdhip64; it must be the HIP runtime this process binds (streams and device
 # pointers are torch's), so torch is loaded before liboctseg_hip.so resolves its libamdhip64 dependency.
