@@ -1041,15 +1041,15 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     HIPCHK(launch_stem_im2col(P->dtype, P->stem_image, E.act(P->col_tensor), P->B, P->H, P->W, tc.C, P->stem_mean, P->stem_std,
                               P->stem_normalize, ws_));
   }
-  // bias gradient
-  if (L.b >= 0)
-    HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, E.st));
   // weight gradient (+ bias gradient) on the side stream: fork after everything that produced dy
   hipStream_t ws_ = E.wst ? E.wst : E.st;
   if (ws_ != E.st) {
     HIPCHK(hipEventRecord(P->ev_fork, E.st));
     HIPCHK(hipStreamWaitEvent(ws_, P->ev_fork, 0));
   }
+  // bias gradient
+  if (L.b >= 0)
+    HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, ws_));
   {
     std::vector<WgradArgs> lw;
     wgrad_launches(g, lw);

@@ -18,12 +18,25 @@ def union(iv):
         else: ce = max(ce, e)
     return tot + ce - cs
 busy = union([(r[1], r[2]) for r in win])
-mf = [(r[1], r[2]) for r in win if any(k in r[0] for k in ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad_mfma'))]
+mf = [(r[1], r[2]) for r in win if any(k in r[0] for k in ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad_mfma', 'thin_conv', 'thin_wgrad'))]
 gaps = []
-iv = sorted((r[1], r[2]) for r in win); ce = iv[0][1]
-for s, e in iv[1:]:
-    if s > ce: gaps.append(s - ce)
-    ce = max(ce, e)
+import collections, re
+pair = collections.Counter(); pairn = collections.Counter()
+short = lambda n: re.sub(r'<.*', '', n.replace('(anonymous namespace)::', '').replace('void ', ''))[:28]
+iv = sorted((r[1], r[2], r[0]) for r in win); ce = iv[0][1]; last = iv[0][2]
+for s, e, nm in iv[1:]:
+    if s > ce:
+        gaps.append(s - ce); pair[(short(last), short(nm))] += s - ce; pairn[(short(last), short(nm))] += 1
+    if e > ce: ce = e; last = nm
 print(f'{nlast} steps: wall {(t1 - t0) / 1e6 / nlast:.3f} ms/step, some kernel running {busy / 1e6 / nlast:.3f} ms/step ({100 * busy / (t1 - t0):.1f} %), '
       f'an MFMA kernel running {union(mf) / 1e6 / nlast:.3f} ms/step; {len(gaps) // nlast} idle gaps per step, '
       f'sum {sum(gaps) / 1e6 / nlast:.3f} ms, median {sorted(gaps)[len(gaps) // 2] / 1e3:.1f} us')
+hist = collections.Counter(min(int(g / 2000) * 2, 40) for g in gaps)
+print('gap histogram (us: count per step):', ' '.join(f'{k}-{k + 2}:{v // nlast}' for k, v in sorted(hist.items())))
+print('idle time by (kernel that ended last -> kernel that starts), ms per step:')
+for k, v in pair.most_common(14):
+    print(f'  {k[0]:28s} -> {k[1]:28s} {v / 1e6 / nlast:7.3f} ms  {pairn[k] // nlast:4d} gaps  {v / pairn[k] / 1e3:5.1f} us each')
+durs = collections.Counter(); cnt = collections.Counter()
+for r in win: durs[short(r[0])] += r[2] - r[1]; cnt[short(r[0])] += 1
+print('kernel time per step (overlapped durations):')
+for k, v in durs.most_common(16): print(f'  {k:28s} {v / 1e6 / nlast:7.3f} ms {cnt[k] // nlast:5d} launches')
