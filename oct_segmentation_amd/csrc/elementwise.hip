@@ -12,41 +12,53 @@
 
 namespace octseg {
 
-// ------------------------------------------------------------------ BatchNorm finalize
-// one block per 32 channels, 32 row lanes; double accumulation -> deterministic.
-// Deterministic two-level reduction of a [rows][C][2] float slab in double.  Grid (ceil(C/32), G), 1024 threads
-// = 32 channels x 32 row lanes; block (bx, by) sums its slice of rows, and the LAST block of column bx to
-// arrive (ticket counter) adds the G partials in index order.  Returns true on the threads (row lane 0,
-// c < C) of that finishing block, with the totals in s1 / s2.  The counter resets itself.
-__device__ __forceinline__ bool slab_sum(const float* __restrict__ slab, int rows, int C, double* part, unsigned* counters,
-                                         double& s1, double& s2) {
-  __shared__ double red[32][33][2];
+// Per-channel totals of a BN partial-sum slab ([rows][C][2] floats, one row per producing workgroup), in double, in a fixed order
+// (deterministic).  A block of 1024 threads owns `cpb` consecutive channels (4..32, a power of two) and walks the rows 1024 / cpb at a time
+// with eight loads in flight per thread; grid.y > 1 splits very long slabs into row groups whose partials the last block to finish (ticket)
+// adds up.  Returns true in the one thread per channel (c < C) that holds the totals in s1 / s2.  The counter resets itself.
+// Why channels-per-block shrink with the slab: conv_mfma's epilogue writes one row per tile, 7744..15488 rows for the 352^2 layers of
+// U-Net++; with 32 channels per block a 64-channel BatchNorm was reduced by two blocks plus row groups behind a ticket whose
+// __threadfence() (an L2 write-back across the XCDs) costs more than the walk -- 40 us per finalize on the forward's dependent chain,
+// 5.1 ms of a 75 ms step, and MORE row groups measured slower still (512 rows per group: 76.8 vs 75.2 ms).
+__device__ __forceinline__ bool slab_sum(const float* __restrict__ slab, int rows, int C, int cpb, double* part, unsigned* counters,
+                                         double& s1, double& s2, int& c) {
+  __shared__ double red[1280][2];
   __shared__ unsigned is_last;
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl, G = gridDim.y;
+  const int sh = __ffs(cpb) - 1, RL = (int)blockDim.x >> sh, pitch = cpb + 1;
+  const int rl = threadIdx.x >> sh, cl = threadIdx.x & (cpb - 1);
+  const int G = gridDim.y;
+  c = blockIdx.x * cpb + cl;
   const int per = (rows + G - 1) / G;
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   s1 = 0.0; s2 = 0.0;
   if (c < C) {
     int r = r0 + rl;
-    for (; r + 96 < r1; r += 128) {   // four independent loads in flight
-      const float2 v0 = *(const float2*)(slab + ((size_t)r * C + c) * 2);
-      const float2 v1 = *(const float2*)(slab + ((size_t)(r + 32) * C + c) * 2);
-      const float2 v2 = *(const float2*)(slab + ((size_t)(r + 64) * C + c) * 2);
-      const float2 v3 = *(const float2*)(slab + ((size_t)(r + 96) * C + c) * 2);
-      s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-      s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    for (; r + 7 * RL < r1; r += 8 * RL) {   // eight independent loads in flight
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *(const float2*)(slab + ((size_t)(r + j * RL) * C + c) * 2);
+      s1 += (((double)v[0].x + (double)v[1].x) + ((double)v[2].x + (double)v[3].x)) + (((double)v[4].x + (double)v[5].x) + ((double)v[6].x + (double)v[7].x));
+      s2 += (((double)v[0].y + (double)v[1].y) + ((double)v[2].y + (double)v[3].y)) + (((double)v[4].y + (double)v[5].y) + ((double)v[6].y + (double)v[7].y));
     }
-    for (; r < r1; r += 32) {
+    for (; r < r1; r += RL) {
       const float2 v = *(const float2*)(slab + ((size_t)r * C + c) * 2);
       s1 += (double)v.x; s2 += (double)v.y;
     }
   }
-  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
-  __syncthreads();
+  // fold the row lanes: lanes >= 8 hand over through LDS, lanes 0..7 add every eighth, lane 0 adds those
+  auto fold = [&]() {
+    if (rl >= 8) { red[rl * pitch + cl][0] = s1; red[rl * pitch + cl][1] = s2; }
+    __syncthreads();
+    if (rl < 8) {
+      for (int k = rl + 8; k < RL; k += 8) { s1 += red[k * pitch + cl][0]; s2 += red[k * pitch + cl][1]; }
+      red[rl * pitch + cl][0] = s1; red[rl * pitch + cl][1] = s2;
+    }
+    __syncthreads();
+    if (rl == 0)
+      for (int k = 1; k < 8 && k < RL; ++k) { s1 += red[k * pitch + cl][0]; s2 += red[k * pitch + cl][1]; }
+  };
+  fold();
   const bool owner = rl == 0 && c < C;
-  if (owner)
-    for (int r = 1; r < 32; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
   if (G == 1) return owner;
   if (owner) {
     part[((size_t)blockIdx.y * C + c) * 2] = s1;
@@ -60,20 +72,31 @@ __device__ __forceinline__ bool slab_sum(const float* __restrict__ slab, int row
     if (is_last) counters[blockIdx.x] = 0u;
   }
   __syncthreads();
-  if (!is_last || !owner) return false;
+  if (!is_last) return false;   // block-uniform
   __threadfence();
   s1 = 0.0; s2 = 0.0;
-  for (int g = 0; g < G; ++g) {
-    s1 += __hip_atomic_load(&part[((size_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s2 += __hip_atomic_load(&part[((size_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return true;
+  if (c < C)
+    for (int g = rl; g < G; g += RL) {
+      s1 += __hip_atomic_load(&part[((size_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s2 += __hip_atomic_load(&part[((size_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  fold();
+  return owner;
 }
-// row groups of the finalize grid: only a long slab is split (the ticket's fence writes the L2 back, which costs
-// more than it saves below a few thousand rows); G * C <= 4096 partials
+// channels per block of the finalize grid: few rows -> 32 (one 256-byte segment per row), long slabs -> down to 4 (a 32-byte sector per
+// row; the slab was just written and sits in L2), so that a thread walks at most a few dozen rows
+static inline int slab_cpb(int rows) {
+  static const int force = getenv("OCTSEG_SLAB_CPB") ? atoi(getenv("OCTSEG_SLAB_CPB")) : 0;   // A/B switch
+  if (force == 4 || force == 8 || force == 16 || force == 32) return force;
+  return rows <= 512 ? 32 : rows <= 2048 ? 16 : rows <= 6144 ? 8 : 4;
+}
+// row groups: only where a thread would still walk more than 256 rows (slabs beyond 64 k rows at 4 channels per block), within the scratch
+// (G * C <= SLAB_PART_CAP partials, 64 tickets)
 static inline int slab_groups(int rows, int C) {
-  int g = rows / 2048;
-  const int cap = 4096 / (C < 32 ? 32 : C);
+  const int cpb = slab_cpb(rows);
+  if ((C + cpb - 1) / cpb > 64) return 1;
+  int g = rows / (256 * (1024 / cpb));
+  const int cap = SLAB_PART_CAP / (C < 32 ? 32 : ((C + 31) / 32) * 32);
   if (g > cap) g = cap;
   if (g > 64) g = 64;
   return g < 1 ? 1 : g;
@@ -82,10 +105,10 @@ static inline int slab_groups(int rows, int C) {
 __global__ __launch_bounds__(1024) void bn_finalize_train_kernel(
     const float* __restrict__ slab, int rows, int C, double count, const float* gamma, const float* beta,
     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
-    float* mean_out, float* rstd_out, double* part, unsigned* counters) {
+    float* mean_out, float* rstd_out, double* part, unsigned* counters, int cpb) {
   double s1, s2;
-  if (!slab_sum(slab, rows, C, part, counters, s1, s2)) return;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  int c;
+  if (!slab_sum(slab, rows, C, cpb, part, counters, s1, s2, c)) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -103,8 +126,9 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
                                     const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float* scale, float* shift, float* mean,
                                     float* rstd, double* part, unsigned* counters, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 31) / 32, slab_groups(rows, C)), dim3(1024), 0, st, slab, rows, C, count,
-                     gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd, part, counters);
+  const int cpb = slab_cpb(rows);
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + cpb - 1) / cpb, slab_groups(rows, C)), dim3(1024), 0, st, slab, rows, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd, part, counters, cpb);
   return hipGetLastError();
 }
 
@@ -361,17 +385,18 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const BnBwdArgs a, const int cpb) {
   double s1, s2;
-  if (!slab_sum(a.slab, a.rows, a.C, a.part, a.counters, s1, s2)) return;
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  int c;
+  if (!slab_sum(a.slab, a.rows, a.C, cpb, a.part, a.counters, s1, s2, c)) return;
   a.dbeta[c] += (float)s1;
   a.dgamma[c] += (float)s2;
   a.coef[2 * c] = (float)(s1 / (double)a.npix);
   a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
 }
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 31) / 32, slab_groups(a.rows, a.C)), dim3(1024), 0, st, a);
+  const int cpb = slab_cpb(a.rows);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + cpb - 1) / cpb, slab_groups(a.rows, a.C)), dim3(1024), 0, st, a, cpb);
   return hipGetLastError();
 }
 

@@ -66,7 +66,8 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
                                     const float* beta, float* running_mean, float* running_var,
                                     float momentum, float eps, float* scale, float* shift, float* mean,
                                     float* rstd, double* part, unsigned* counters, hipStream_t st);
-// `part` (4096 x 2 doubles) and `counters` (64 zeroed uints) are the scratch of the two-level slab reduction.
+// `part` (SLAB_PART_CAP x 2 doubles) and `counters` (64 zeroed uints) are the scratch of the two-level slab reduction.
+constexpr int SLAB_PART_CAP = 16384;
 // eval: scale/shift from the running statistics.
 hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift,

@@ -659,7 +659,7 @@ static int build_plan(octseg_plan* P) {
   // the BN backward reduce uses up to 1024 slab rows
   for (auto& bn : P->bns) slab = std::max(slab, (size_t)1024 * bn.C * 2 * sizeof(float));
   P->slab_off = off; P->slab_bytes = align_up(slab); off += 2 * align_up(slab);          // one slab per forward lane
-  P->fin_part_off = off; off += 2 * align_up(4096 * 2 * sizeof(double));   // two-level slab reduction scratch (per lane)
+  P->fin_part_off = off; off += 2 * align_up((size_t)SLAB_PART_CAP * 2 * sizeof(double));   // two-level slab reduction scratch (per lane)
   P->fin_cnt_off = off; off += align_up(2 * 64 * sizeof(unsigned));
   P->bwd_part_off = off; off += align_up((size_t)8 * 32 * 4096 * sizeof(double));   // [column][group][256 vectors x 8 channels x 2]
   P->bwd_cnt_off = off; off += align_up((size_t)8 * 33 * 32 * sizeof(unsigned));   // one 128-byte line per ticket
@@ -824,7 +824,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
     hipStream_t st = lst[lane];
     const int stamp = (lane << 24) | (enq[lane] + 1);
     float* slab_l = (float*)(E.ws + P->slab_off + (size_t)lane * P->slab_bytes);
-    double* part_l = (double*)(E.ws + P->fin_part_off) + (size_t)lane * 4096 * 2;
+    double* part_l = (double*)(E.ws + P->fin_part_off) + (size_t)lane * SLAB_PART_CAP * 2;
     unsigned* cnt_l = (unsigned*)(E.ws + P->fin_cnt_off) + lane * 64;
     if (lane == 1 && enq[1] == 0) { rc = need(1, 1); if (rc) return rc; }   // the side lane starts behind the setup work
     switch (op.kind) {
