@@ -41,7 +41,8 @@ WORKLOADS = {
     'linknet_r50_704': ('linknet', 'resnet50', 2, 704),
     'unet_r50_704': ('unet', 'resnet50', 1, 704),
     'unet_r18_256': ('unet', 'resnet18', 1, 256),
-    'fpn_r50_704': ('fpn', 'resnet50', 1, 704),       # a sweep architecture outside BASELINE's three
+    'fpn_r50_704': ('fpn', 'resnet50', 1, 704),       # sweep architectures outside BASELINE's three
+    'deeplabv3plus_r50_704': ('deeplabv3plus', 'resnet50', 1, 704),
 }
 
 

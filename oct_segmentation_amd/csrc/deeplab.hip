@@ -1,0 +1,303 @@
+// deeplab.hip -- the HBM-bound kernels that the DeepLabV3+ decoder adds to the hot path (gfx950): depthwise (dilated) 3x3 convolution
+// forward / data gradient / weight gradient, the space <-> batch permutation that turns ResNet layer4 at dilation 2 into ordinary 3x3
+// convolutions, image pooling (global mean) and its broadcast, element-wise dropout with an injected keep mask, and the plain bilinear
+// (align_corners=True) resample between NHWC tensors.
+//
+// Reference: `DeepLabV3Plus` is one of the architectures the reference sweeps (configs/tune.yaml:9-18 -> smp.create_model(arch=...),
+// src/models/smp/model.py:38-44; DeepLabV3Plus/resnet101 is a per-class winner in eval/tuning/configs_best.xlsx); the arithmetic is
+// smp 0.3.3 decoders/deeplabv3/{model,decoder}.py + base/modules.py SeparableConv2d + encoders/_base.py make_dilated, restated in
+// oracle/nets.py (DeepLabV3PlusDecoder, ResNetEncoder.make_dilated).
+//
+// Dilation without a dilated kernel: a 3x3 conv with dilation 2 and padding 2 only ever combines pixels of equal row / column parity, and
+// on each of the four parity sub-grids it IS a 3x3 conv with padding 1 (the zero border of the fine map is the zero border of every
+// sub-grid).  make_dilated(16) sets stride 1 / dilation 2 on every conv of layer4, 1x1 convs and BatchNorm are position-blind, so layer4
+// runs unchanged on the [4N][H/2][W/2] re-arrangement of layer3's output and its result is re-arranged back for the ASPP.
+// All tensors NHWC, 16-byte vectors, f32 arithmetic; the only float atomics are the depthwise weight gradients (one per block and weight).
+#include "common.h"
+#include "ev.h"
+#include "kernels.h"
+
+namespace octseg {
+
+#define DL_DISPATCH(KERNEL, grid, ...)                                                          \
+  do {                                                                                          \
+    if (dtype == DT_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(256), 0, st, __VA_ARGS__);      \
+    else if (dtype == DT_F16) hipLaunchKernelGGL(KERNEL<f16_t>, grid, dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<bf16_t>, grid, dim3(256), 0, st, __VA_ARGS__);                     \
+  } while (0)
+
+template <typename T>
+static __device__ __forceinline__ void put(void* dst, size_t idx, float* x, int accum) {
+  constexpr int VEC = EV<T>::VEC;
+  if (accum) {
+    float o[VEC];
+    EV<T>::unpack(ldv<T>(dst, idx), o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] += o[i];
+  }
+  stv<T>(dst, idx, EV<T>::pack(x));
+}
+
+// ------------------------------------------------------------------ space <-> batch (dilation 2 as parity sub-grids)
+// fine [N][H][W][C], coarse [4N][H/2][W/2][C], coarse image = 4 n + 2 (y & 1) + (x & 1).  to_coarse: coarse = fine; else fine (+)= coarse.
+template <typename T>
+__global__ __launch_bounds__(256) void parity_permute_kernel(const void* src, void* dst, int N, int H, int W, int vpc, int to_coarse, int accum) {
+  constexpr int VEC = EV<T>::VEC;
+  const size_t nvec = (size_t)N * H * W * vpc;
+  const int H2 = H >> 1, W2 = W >> 1;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    const size_t c = ((((size_t)n * 4 + (y & 1) * 2 + (x & 1)) * H2 + (y >> 1)) * W2 + (x >> 1)) * vpc + cv;
+    float f[VEC];
+    EV<T>::unpack(ldv<T>(src, to_coarse ? v : c), f);
+    put<T>(dst, to_coarse ? c : v, f, accum);
+  }
+}
+hipError_t launch_parity_permute(int dtype, const void* src, void* dst, int N, int H, int W, int C, int to_coarse, int accum, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || (H & 1) || (W & 1)) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * H * W * (C / vec);
+  DL_DISPATCH(parity_permute_kernel, dim3(grid_for(nvec, 256)), src, dst, N, H, W, C / vec, to_coarse, accum);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ depthwise 3x3 (dilation d, padding d, stride 1)
+// out[n][y][x][oc0 + c] (+)= sum_t w[t'][wc0 + c] * in[n][y + d (r - 1)][x + d (s - 1)][ic0 + c],  t = 3 r + s, t' = flip ? 8 - t : t
+// (flip = the data gradient: correlation with the mirrored kernel).  Weights: the fp32 master [3][3][Cw] (tap-major, channel-contiguous).
+// `in` / `out` may be channel slices of wider tensors (inC / outC = their channel counts): torch.cat never materialises.
+struct DwArgs {
+  const void* in; void* out; const float* w;
+  int inC, ic0, outC, oc0, wC, wc0;
+  int N, H, W, C, dil, flip, accum;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dw_conv_kernel(const DwArgs a) {
+  constexpr int VEC = EV<T>::VEC;
+  const int vpc = a.C / VEC, ivs = a.inC / VEC, ovs = a.outC / VEC, iv0 = a.ic0 / VEC, ov0 = a.oc0 / VEC;
+  const size_t nvec = (size_t)a.N * a.H * a.W * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int x = (int)(p % a.W); p /= a.W;
+    const int y = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + a.dil * (t / 3 - 1), xx = x + a.dil * (t % 3 - 1);
+      if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(a.in, (((size_t)n * a.H + yy) * a.W + xx) * ivs + iv0 + cv), f);
+      const float* wt = a.w + (size_t)(a.flip ? 8 - t : t) * a.wC + a.wc0 + cv * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wt[i], f[i], acc[i]);
+    }
+    put<T>(a.out, (((size_t)n * a.H + y) * a.W + x) * ovs + ov0 + cv, acc, a.accum);
+  }
+}
+static bool dw_ok(int dtype, const DwArgs& a) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  return a.C % vec == 0 && a.inC % vec == 0 && a.outC % vec == 0 && a.ic0 % vec == 0 && a.oc0 % vec == 0 && a.wc0 % 4 == 0 && a.wC % 4 == 0 &&
+         a.dil >= 1 && a.ic0 + a.C <= a.inC && a.oc0 + a.C <= a.outC && a.wc0 + a.C <= a.wC;
+}
+hipError_t launch_dw_conv(int dtype, const void* in, int inC, int ic0, void* out, int outC, int oc0, const float* w, int wC, int wc0, int N, int H,
+                          int W, int C, int dil, int flip, int accum, hipStream_t st) {
+  DwArgs a{in, out, w, inC, ic0, outC, oc0, wC, wc0, N, H, W, C, dil, flip, accum};
+  if (!dw_ok(dtype, a)) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * H * W * (C / (dtype == DT_F32 ? 4 : 8));
+  DL_DISPATCH(dw_conv_kernel, dim3(grid_for(nvec, 256)), a);
+  return hipGetLastError();
+}
+
+// weight gradient: dw[t][wc0 + c] += sum_{n, y, x} gout[n][y][x][oc0 + c] * in[n][y + d (r - 1)][x + d (s - 1)][ic0 + c].
+// Block (bx, by): channel vectors [256 by, 256 by + nv), thread (r, v) owns vector v of the pixels r, r + rows, ... of its share; nine
+// taps x VEC sums in registers, folded over the rows through LDS one tap at a time, one atomic per block and weight.
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwArgs a, float* dw) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int vpc = a.C / VEC, ivs = a.inC / VEC, ovs = a.outC / VEC, iv0 = a.ic0 / VEC, ov0 = a.oc0 / VEC;
+  const int v0 = blockIdx.y * 256, nv = min(256, vpc - v0), rows = 256 / nv;
+  const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
+  float acc[9][VEC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+  const size_t npix = (size_t)a.N * a.H * a.W;
+  if (r < rows)
+    for (size_t p = (size_t)blockIdx.x * rows + r; p < npix; p += (size_t)gridDim.x * rows) {
+      const int x = (int)(p % a.W);
+      const int y = (int)((p / a.W) % a.H);
+      const size_t n = p / ((size_t)a.W * a.H);
+      float g[VEC];
+      EV<T>::unpack(ldv<T>(a.out, p * ovs + ov0 + v0 + cv), g);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + a.dil * (t / 3 - 1), xx = x + a.dil * (t % 3 - 1);
+        if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+        float f[VEC];
+        EV<T>::unpack(ldv<T>(a.in, ((n * a.H + yy) * a.W + xx) * ivs + iv0 + v0 + cv), f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[t][i] = fmaf(g[i], f[i], acc[t][i]);
+      }
+    }
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (r < rows)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[(r * nv + cv) * VEC + i] = acc[t][i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < nv * VEC; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < rows; ++k) s += red[k * nv * VEC + c];
+      atomicAdd(dw + (size_t)t * a.wC + a.wc0 + v0 * VEC + c, s);
+    }
+  }
+}
+hipError_t launch_dw_wgrad(int dtype, const void* in, int inC, int ic0, const void* gout, int goC, int oc0, float* dw, int wC, int wc0, int N, int H,
+                           int W, int C, int dil, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  DwArgs a{in, const_cast<void*>(gout), nullptr, inC, ic0, goC, oc0, wC, wc0, N, H, W, C, dil, 0, 0};
+  if (!dw_ok(dtype, a)) return hipErrorInvalidValue;
+  const int vpc = C / (dtype == DT_F32 ? 4 : 8);
+  const int nv = vpc < 256 ? vpc : 256, rows = 256 / nv;
+  const size_t npix = (size_t)N * H * W;
+  size_t gx = (npix + (size_t)rows * 64 - 1) / ((size_t)rows * 64);
+  if (gx > 256) gx = 256;
+  if (gx < 1 || deterministic_mode()) gx = 1;
+  const dim3 grid((unsigned)gx, (unsigned)((vpc + 255) / 256));
+  if (dtype == DT_F32) hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, a, dw);
+  else hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, a, dw);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ per-image channel sums and their broadcast
+// out[n][c] = sum_p in[n][p][c] / div   (AdaptiveAvgPool2d(1): div = HW; gradient of the broadcast below: div = 1).
+// grid (ceil(vpc / 256), N): deterministic (one block per image and channel chunk, fixed order).
+template <typename T>
+__global__ __launch_bounds__(256) void image_sum_kernel(const void* in, void* out, int HW, int vpc, float div) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int v0 = blockIdx.x * 256, nv = min(256, vpc - v0), rows = 256 / nv;
+  const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
+  const size_t n = blockIdx.y;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  if (r < rows)
+    for (int p = r; p < HW; p += rows) {
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(in, (n * HW + p) * vpc + v0 + cv), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += f[i];
+    }
+  if (r < rows)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(r * nv + cv) * VEC + i] = s[i];
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rows; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += red[(k * nv + cv) * VEC + i];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] /= div;   // (a division, as torch's mean)
+    stv<T>(out, n * vpc + v0 + cv, EV<T>::pack(s));
+  }
+}
+hipError_t launch_image_sum(int dtype, const void* in, void* out, int N, int HW, int C, float div, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0) return hipErrorInvalidValue;
+  const int vpc = C / vec;
+  DL_DISPATCH(image_sum_kernel, dim3((vpc + 255) / 256, N), in, out, HW, vpc, div);
+  return hipGetLastError();
+}
+// out[n][p][c] (+)= scale * in[n][c]   (F.interpolate of a 1x1 map to any size, either align_corners: a broadcast; gradient of the mean)
+template <typename T>
+__global__ __launch_bounds__(256) void image_bcast_kernel(const void* in, void* out, size_t HW, int vpc, float scale, int accum, size_t nvec) {
+  constexpr int VEC = EV<T>::VEC;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    const size_t n = v / (HW * vpc);
+    float f[VEC];
+    EV<T>::unpack(ldv<T>(in, n * vpc + cv), f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] *= scale;
+    put<T>(out, v, f, accum);
+  }
+}
+hipError_t launch_image_bcast(int dtype, const void* in, void* out, int N, int HW, int C, float scale, int accum, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * HW * (C / vec);
+  DL_DISPATCH(image_bcast_kernel, dim3(grid_for(nvec, 256)), in, out, (size_t)HW, C / vec, scale, accum, nvec);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ element-wise dropout with an injected keep mask (nn.Dropout(0.5) of ASPP.project)
+// out = in * keep * mscale;  keep: float 0 / 1, NHWC like the tensor (nullptr: copy).  The gradient is the same kernel on the gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void drop_elem_kernel(const void* in, const float* keep, float mscale, void* out, size_t nvec) {
+  constexpr int VEC = EV<T>::VEC;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    float f[VEC];
+    EV<T>::unpack(ldv<T>(in, v), f);
+    if (keep != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) f[i] *= keep[v * VEC + i] * mscale;
+    }
+    stv<T>(out, v, EV<T>::pack(f));
+  }
+}
+hipError_t launch_drop_elem(int dtype, const void* in, const float* keep, float mscale, void* out, size_t numel, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (numel % vec != 0) return hipErrorInvalidValue;
+  const size_t nvec = numel / vec;
+  DL_DISPATCH(drop_elem_kernel, dim3(grid_for(nvec, 256)), in, keep, mscale, out, nvec);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ bilinear resample by `up`, align_corners=True (nn.UpsamplingBilinear2d), NHWC -> NHWC
+// torch's source index: scale = (in - 1) / (out - 1) in float, x = scale * o, i0 = (int)x, lambda1 = x - i0 (as fpn.hip; the adjoint there
+// uses the same expressions, launch_bilinear_adjoint is this kernel's backward)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_kernel(const void* in, void* out, int N, int H, int W, int vpc, int up, float sy, float sx) {
+  constexpr int VEC = EV<T>::VEC;
+  const int OH = H * up, OW = W * up;
+  const size_t nvec = (size_t)N * OH * OW * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const size_t n = p / OH;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1, wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    float a00[VEC], a01[VEC], a10[VEC], a11[VEC], o[VEC];
+    EV<T>::unpack(ldv<T>(in, ((n * H + y0) * W + x0) * vpc + cv), a00);
+    EV<T>::unpack(ldv<T>(in, ((n * H + y0) * W + x1) * vpc + cv), a01);
+    EV<T>::unpack(ldv<T>(in, ((n * H + y1) * W + x0) * vpc + cv), a10);
+    EV<T>::unpack(ldv<T>(in, ((n * H + y1) * W + x1) * vpc + cv), a11);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = wy0 * (wx0 * a00[i] + wx1 * a01[i]) + wy1 * (wx0 * a10[i] + wx1 * a11[i]);
+    stv<T>(out, v, EV<T>::pack(o));
+  }
+}
+hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H, int W, int C, int up, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || up < 2) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * H * up * W * up * (C / vec);
+  const float sy = H * up > 1 ? (float)(H - 1) / (float)(H * up - 1) : 0.f, sx = W * up > 1 ? (float)(W - 1) / (float)(W * up - 1) : 0.f;
+  DL_DISPATCH(bilinear_up_kernel, dim3(grid_for(nvec, 256)), in, out, N, H, W, C / vec, up, sy, sx);
+  return hipGetLastError();
+}
+
+}  // namespace octseg

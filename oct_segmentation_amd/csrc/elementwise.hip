@@ -8,6 +8,7 @@
 #include "ev.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 namespace octseg {
@@ -129,6 +130,47 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
   const int cpb = slab_cpb(rows);
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + cpb - 1) / cpb, slab_groups(rows, C)), dim3(1024), 0, st, slab, rows, C, count,
                      gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd, part, counters, cpb);
+  return hipGetLastError();
+}
+
+// BatchNorm statistics of a tensor with only a handful of values per channel (DeepLabV3+'s pooled ASPP branch: B values), two-pass in
+// double straight from the conv output.  The slab path's E[x^2] - E[x]^2 over float partial sums is fine for feature maps (variance
+// comparable to mean^2) but loses the variance of B nearly equal numbers: 1 % of rstd there, which the fp32 parity tests see as
+// noise in every encoder gradient.  One thread per channel; same outputs as bn_finalize_train_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_small_kernel(const void* y, int count, int C, const float* gamma, const float* beta,
+                                                                float* running_mean, float* running_var, float momentum, float eps,
+                                                                float* scale, float* shift, float* mean_out, float* rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  auto val = [&](int i) -> double {
+    if (sizeof(T) == 4) return (double)((const float*)y)[(size_t)i * C + c];
+    if (std::is_same<T, f16_t>::value) return (double)(float)((const _Float16*)y)[(size_t)i * C + c];
+    return (double)__uint_as_float((unsigned)((const unsigned short*)y)[(size_t)i * C + c] << 16);
+  };
+  double m = 0.0;
+  for (int i = 0; i < count; ++i) m += val(i);
+  m /= (double)count;
+  double v = 0.0;
+  for (int i = 0; i < count; ++i) { const double d = val(i) - m; v += d * d; }
+  const double var = v / (double)count;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  mean_out[c] = (float)m;
+  rstd_out[c] = rstd;
+  const double unbiased = count > 1 ? v / (double)(count - 1) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+hipError_t launch_bn_finalize_small(int dtype, const void* y, int count, int C, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                                    hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  const dim3 grid((C + 255) / 256);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_finalize_small_kernel<float>, grid, dim3(256), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+  else hipLaunchKernelGGL(bn_finalize_small_kernel<bf16_t>, grid, dim3(256), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
   return hipGetLastError();
 }
 

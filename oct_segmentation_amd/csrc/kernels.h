@@ -69,6 +69,11 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
 // `part` (SLAB_PART_CAP x 2 doubles) and `counters` (64 zeroed uints) are the scratch of the two-level slab reduction.
 constexpr int SLAB_PART_CAP = 16384;
 // eval: scale/shift from the running statistics.
+// statistics of a tensor with <= BN_SMALL_COUNT values per channel, two-pass in double from the conv output itself (no slab)
+constexpr int BN_SMALL_COUNT = 64;
+hipError_t launch_bn_finalize_small(int dtype, const void* y, int count, int C, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                                    hipStream_t st);
 hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift,
                                    hipStream_t st);
@@ -177,6 +182,17 @@ hipError_t launch_merge_drop(int dtype, const void* a0, const void* a1, const vo
                              int N, size_t HW, int C, hipStream_t st);
 hipError_t launch_drop_bwd(int dtype, const void* gout, const float* m, float mscale, void* gin, int N, size_t HW, int C, hipStream_t st);
 hipError_t launch_bilinear_nchw(const float* z, float* out, int NC, int H, int W, int up, hipStream_t st);                          // NCHW f32, align_corners=True
+
+// ---- DeepLabV3+ (deeplab.hip)
+hipError_t launch_parity_permute(int dtype, const void* src, void* dst, int N, int H, int W, int C, int to_coarse, int accum, hipStream_t st);   // fine [N][H][W][C] <-> coarse [4N][H/2][W/2][C]
+hipError_t launch_dw_conv(int dtype, const void* in, int inC, int ic0, void* out, int outC, int oc0, const float* w, int wC, int wc0, int N, int H,
+                          int W, int C, int dil, int flip, int accum, hipStream_t st);                                                          // depthwise 3x3, dilation = padding = dil
+hipError_t launch_dw_wgrad(int dtype, const void* in, int inC, int ic0, const void* gout, int goC, int oc0, float* dw, int wC, int wc0, int N, int H,
+                           int W, int C, int dil, hipStream_t st);
+hipError_t launch_image_sum(int dtype, const void* in, void* out, int N, int HW, int C, float div, hipStream_t st);                              // out [N][C] = sum over pixels / div
+hipError_t launch_image_bcast(int dtype, const void* in, void* out, int N, int HW, int C, float scale, int accum, hipStream_t st);              // out [N][HW][C] (+)= scale * in [N][C]
+hipError_t launch_drop_elem(int dtype, const void* in, const float* keep, float mscale, void* out, size_t numel, hipStream_t st);                // out = in * keep * mscale
+hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H, int W, int C, int up, hipStream_t st);                         // NHWC, align_corners=True
 
 // serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,

@@ -319,6 +319,49 @@ struct Builder {
     P->ops.push_back(op);
     return o;
   }
+  // ---- DeepLabV3+ pieces (smp decoders/deeplabv3, restated in oracle/nets.py; kernels in deeplab.hip)
+  int parity(int in, bool to_coarse) {   // [N][H][W] -> [4N][H/2][W/2] parity sub-grids (a dilation-2 3x3 is a plain 3x3 on them), or back
+    const TensorInfo& t = P->tensors[in];
+    const int o = to_coarse ? tensor(t.N * 4, t.H / 2, t.W / 2, t.C) : tensor(t.N / 4, t.H * 2, t.W * 2, t.C);
+    Op op; op.kind = OP_PARITY; op.in = in; op.out = o; op.up = to_coarse ? 1 : 0;
+    P->ops.push_back(op);
+    return o;
+  }
+  int dw_param(const std::string& name, int C) { return param(name + ".weight", OCTSEG_P_CONV, 3, 3, C, 1, 0); }   // torch [C][1][3][3]
+  void dw(int in, int out, int oc0, int dwp, int wc0, int dil) {   // depthwise 3x3 of `in` into channels [oc0, oc0 + C_in) of `out`
+    const TensorInfo& t = P->tensors[in];
+    Op op; op.kind = OP_DW; op.in = in; op.out = out; op.oc0 = oc0; op.dwp = dwp; op.wc0 = wc0; op.up = dil;
+    P->ops.push_back(op);
+    P->fwd_macs += (double)t.N * t.H * t.W * t.C * 9.0;
+  }
+  int gap(int in) {                       // AdaptiveAvgPool2d(1)
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, 1, 1, t.C);
+    Op op; op.kind = OP_GAP; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int bcast(int in, int H, int W) {       // F.interpolate of a 1x1 map to H x W
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, H, W, t.C);
+    Op op; op.kind = OP_BCAST; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int drope(int in) {                     // nn.Dropout (element-wise), keep mask injected
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_DROPE; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int upb(int in, int up) {               // nn.UpsamplingBilinear2d(scale_factor=up)
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H * up, t.W * up, t.C);
+    Op op; op.kind = OP_UPB; op.in = in; op.out = o; op.up = up;
+    P->ops.push_back(op);
+    return o;
+  }
   int merge4(const int (&ins)[4]) {   // MergeBlock('add') + Dropout2d: every summand receives the same gradient -> one shared buffer
     const TensorInfo& t = P->tensors[ins[0]];
     const int o = tensor(t.N, t.H, t.W, t.C);
@@ -332,7 +375,9 @@ struct Builder {
 Value mat(int t) { Value v; v.t = t; v.bn = -1; return v; }
 
 // torchvision ResNet; returns materialised features f1..f5
-std::vector<int> build_resnet(Builder& b, const std::string& enc) {
+// dilate4: smp's make_dilated(output_stride=16) -- every conv of layer4 at stride 1 / dilation 2.  Built as the ordinary layer4 (stride 1)
+// on the parity re-arrangement of layer3's output (deeplab.hip header): no dilated conv kernel exists or is needed.
+std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 = false) {
   octseg_plan* P = b.P;
   const bool bottleneck = enc == "resnet50" || enc == "resnet101" || enc == "resnet152";
   int nblocks[4];
@@ -353,8 +398,10 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc) {
   for (int li = 0; li < 4; ++li) {
     const int planes = planes_l[li];
     const int exp = bottleneck ? 4 : 1;
+    const bool dil = dilate4 && li == 3;
+    if (dil) x = b.parity(x, true);
     for (int bi = 0; bi < nblocks[li]; ++bi) {
-      const int stride = (bi == 0 && li > 0) ? 2 : 1;
+      const int stride = (bi == 0 && li > 0 && !dil) ? 2 : 1;
       const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
       const bool ds = (stride != 1) || (inplanes != planes * exp);
       Value last;
@@ -371,6 +418,7 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc) {
       x = b.bn_act(last, res, -1, true);
       inplanes = planes * exp;
     }
+    if (dil) x = b.parity(x, false);
     feats.push_back(x);
   }
   return feats;  // f1 (S/2) .. f5 (S/32)
@@ -462,7 +510,7 @@ static void assign_lanes(octseg_plan* P) {
 
 static int build_plan(octseg_plan* P) {
   Builder b{P, dtype_size(P->dtype)};
-  std::vector<int> f = build_resnet(b, P->encoder);  // f[0]=f1 .. f[4]=f5
+  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus");  // f[0]=f1 .. f[4]=f5
   std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
   std::vector<int> ench;
   for (int t : fr) ench.push_back(P->tensors[t].C);
@@ -538,13 +586,53 @@ static int build_plan(octseg_plan* P) {
       seg[i] = t;
     }
     x = mat(b.merge4(seg));
+  } else if (P->arch == "deeplabv3plus") {
+    // smp DeepLabV3Plus (reference sweep, configs/tune.yaml:9-18) with its defaults: encoder_output_stride 16, decoder_channels 256,
+    // atrous rates (12, 24, 36), 48-channel high-resolution branch from the stride-4 feature, head = 1x1 conv + UpsamplingBilinear2d(4).
+    head_k = 1;
+    P->head_up = 4;
+    P->dropout_p = 0.5f;
+    const int X = f[4];                       // stride 16 (layer4 dilated)
+    const TensorInfo tx = P->tensors[X];
+    const std::string A = "decoder.aspp.0";
+    std::vector<ConvSrc> cat;
+    cat.push_back({b.conv(A + ".convs.0.0", {{mat(X), 0}}, 256, 1, 1, 0, A + ".convs.0.1", false), 0});
+    const int rates[3] = {12, 24, 36};
+    for (int i = 0; i < 3; ++i) {             // ASPPSeparableConv: depthwise dilated 3x3, pointwise 1x1, BN, ReLU
+      const std::string pre = A + ".convs." + std::to_string(i + 1);
+      const int wp = b.dw_param(pre + ".0.0", tx.C);
+      const int t = b.tensor(tx.N, tx.H, tx.W, tx.C);
+      b.dw(X, t, 0, wp, 0, rates[i]);
+      cat.push_back({b.conv(pre + ".0.1", {{mat(t), 0}}, 256, 1, 1, 0, pre + ".1", false), 0});
+    }
+    {                                         // ASPPPooling: mean, 1x1 conv, BN (over the batch only), ReLU, resize = broadcast
+      const std::string pre = A + ".convs.4";
+      const int g = b.gap(X);
+      const Value v = b.conv(pre + ".1", {{mat(g), 0}}, 256, 1, 1, 0, pre + ".2", false);
+      cat.push_back({mat(b.bcast(b.bn_act(v, Value(), -1, true), tx.H, tx.W)), 0});
+    }
+    const Value pr = b.conv(A + ".project.0", cat, 256, 1, 1, 0, A + ".project.1", false);
+    const int pd = b.drope(b.bn_act(pr, Value(), -1, true));
+    const int wp1 = b.dw_param("decoder.aspp.1.0", 256);
+    const int t1 = b.tensor(tx.N, tx.H, tx.W, 256);
+    b.dw(pd, t1, 0, wp1, 0, 1);
+    const Value a2 = b.conv("decoder.aspp.1.1", {{mat(t1), 0}}, 256, 1, 1, 0, "decoder.aspp.2", false);
+    const int au = b.upb(b.bn_act(a2, Value(), -1, true), 4);
+    const Value h1 = b.conv("decoder.block1.0", {{mat(f[1]), 0}}, 48, 1, 1, 0, "decoder.block1.1", false);
+    const int hm = b.bn_act(h1, Value(), -1, true);
+    const int wp2 = b.dw_param("decoder.block2.0.0", 256 + 48);
+    const TensorInfo tu = P->tensors[au];
+    const int t2 = b.tensor(tu.N, tu.H, tu.W, 256 + 48);     // torch.cat([aspp, high_res]) exists only as the depthwise conv's output
+    b.dw(au, t2, 0, wp2, 0, 1);
+    b.dw(hm, t2, 256, wp2, 256, 1);
+    x = b.conv("decoder.block2.0.1", {{mat(t2), 0}}, 256, 1, 1, 0, "decoder.block2.1", false);
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (P->arch != "fpn") assign_lanes(P);
+  if (P->arch != "fpn" && P->arch != "deeplabv3plus") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -897,7 +985,10 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         const float* beta = E.params + P->params[b.beta].off;
         rc = need(lane, tseq[b.y]);   // same lane as its conv by construction; kept for safety
         if (rc) return rc;
-        if (E.train)
+        if (E.train && b.count <= (double)BN_SMALL_COUNT)   // a handful of values per channel (pooled ASPP branch): exact two-pass statistics
+          HIPCHK(launch_bn_finalize_small(P->dtype, E.act(b.y), (int)b.count, b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f,
+                                          1e-5f, E.bn_scale(op.bn), E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), st));
+        else if (E.train)
           HIPCHK(launch_bn_finalize_train(slab_l, b.rows, b.C, b.count, gamma, beta,
                                           E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f, 1e-5f, E.bn_scale(op.bn),
                                           E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), part_l, cnt_l, st));
@@ -948,6 +1039,43 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           return fail(OCTSEG_BAD_ARG, "FPN training forward: no Dropout2d keep mask set (octseg_plan_set_dropout: device float [B][128] of 0 / 1)");
         HIPCHK(launch_merge_drop(P->dtype, E.act(op.ins[0]), E.act(op.ins[1]), E.act(op.ins[2]), E.act(op.ins[3]),
                                  E.train ? P->dropout_keep : nullptr, 1.0f / (1.0f - P->dropout_p), E.act(op.out), t.N, (size_t)t.H * t.W, t.C, st));
+        break;
+      }
+      case OP_PARITY: {
+        const TensorInfo& tf = P->tensors[op.up ? op.in : op.out];   // the fine tensor
+        HIPCHK(launch_parity_permute(P->dtype, E.act(op.in), E.act(op.out), tf.N, tf.H, tf.W, tf.C, op.up, 0, st));
+        break;
+      }
+      case OP_DW: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        const ParamInfo& w = P->params[op.dwp];
+        HIPCHK(launch_dw_conv(P->dtype, E.act(op.in), ti.C, 0, E.act(op.out), to.C, op.oc0, E.params + w.off, w.O, op.wc0, ti.N, ti.H, ti.W, ti.C,
+                              op.up, 0, 0, st));
+        break;
+      }
+      case OP_GAP: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_image_sum(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H * t.W, t.C, (float)(t.H * t.W), st));
+        break;
+      }
+      case OP_BCAST: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_image_bcast(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H * t.W, t.C, 1.f, 0, st));
+        break;
+      }
+      case OP_DROPE: {
+        const TensorInfo& t = P->tensors[op.out];
+        if (E.train && P->dropout_keep == nullptr)
+          return fail(OCTSEG_BAD_ARG, "DeepLabV3+ training forward: no dropout keep mask set (octseg_plan_set_dropout: device float "
+                                      "[B][H/16][W/16][256] of 0 / 1, NHWC)");
+        HIPCHK(launch_drop_elem(P->dtype, E.act(op.in), E.train ? P->dropout_keep : nullptr, 1.0f / (1.0f - P->dropout_p), E.act(op.out),
+                                (size_t)t.N * t.H * t.W * t.C, st));
+        break;
+      }
+      case OP_UPB: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_bilinear_up(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, op.up, st));
         break;
       }
       case OP_UPLOGITS: {
@@ -1159,6 +1287,7 @@ static void slice_plan(const octseg_plan* P, SliceCtx& S) {
     if (op.kind == OP_CONV) { touch(oi, P->convs[op.conv].w); touch(oi, P->convs[op.conv].b); }
     else if (op.kind == OP_BN_FIN) { if (P->bns[op.bn].lazy) { touch(oi, P->bns[op.bn].gamma); touch(oi, P->bns[op.bn].beta); } }
     else if (op.kind == OP_GN) { touch(oi, P->gns[op.gn].gamma); touch(oi, P->gns[op.gn].beta); }
+    else if (op.kind == OP_DW) touch(oi, op.dwp);
     else if (op.kind == OP_BN_ACT) {
       touch(oi, P->bns[op.y.bn].gamma); touch(oi, P->bns[op.y.bn].beta);
       if (op.res.t >= 0 && op.res.bn >= 0) { touch(oi, P->bns[op.res.bn].gamma); touch(oi, P->bns[op.res.bn].beta); }
@@ -1257,6 +1386,50 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
           const int acc = E.claim(op.post);
           HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, acc ? 0 : 1, E.st));
         }
+        break;
+      }
+      case OP_UPB: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_bilinear_adjoint(P->dtype, E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, op.up, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_DROPE: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_drop_elem(P->dtype, E.grad(op.out), P->dropout_keep, 1.0f / (1.0f - P->dropout_p), E.grad(op.in),
+                                (size_t)t.N * t.H * t.W * t.C, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_BCAST: {      // gradient of a broadcast: per-image sums
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_image_sum(P->dtype, E.grad(op.out), E.grad(op.in), t.N, t.H * t.W, t.C, 1.f, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_GAP: {        // gradient of the mean: broadcast / HW, next to the other consumers of the ASPP input
+        const TensorInfo& t = P->tensors[op.in];
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_image_bcast(P->dtype, E.grad(op.out), E.grad(op.in), t.N, t.H * t.W, t.C, 1.f / (float)(t.H * t.W), acc, E.st));
+        break;
+      }
+      case OP_DW: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        const ParamInfo& w = P->params[op.dwp];
+        HIPCHK(launch_dw_wgrad(P->dtype, E.act(op.in), ti.C, 0, E.grad(op.out), to.C, op.oc0, E.grads + w.off, w.O, op.wc0, ti.N, ti.H, ti.W, ti.C,
+                               op.up, E.st));
+        if (ti.need_grad) {
+          const int acc = E.claim(op.in);
+          HIPCHK(launch_dw_conv(P->dtype, E.grad(op.out), to.C, op.oc0, E.grad(op.in), ti.C, 0, E.params + w.off, w.O, op.wc0, ti.N, ti.H, ti.W,
+                                ti.C, op.up, 1, acc, E.st));
+        }
+        break;
+      }
+      case OP_PARITY: {     // the inverse permutation of the gradient
+        const TensorInfo& tf = P->tensors[op.up ? op.in : op.out];
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_parity_permute(P->dtype, E.grad(op.out), E.grad(op.in), tf.N, tf.H, tf.W, tf.C, op.up ? 0 : 1, acc, E.st));
         break;
       }
       case OP_UPLOGITS: {   // adjoint of the x4 bilinear resample: dL/dlogits (NHWC, padded channels) -> gradient of the stride-4 map

@@ -73,7 +73,14 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               OP_UP2,        // out = nearest x2 of in (materialised; a skip conv accumulates into it)
               OP_GN,         // out = resample(relu(groupnorm(in))), up = 1 | 2 (bilinear, align_corners)
               OP_MERGE,      // out = (ins[0] + .. + ins[3]) * dropout keep mask
-              OP_UPLOGITS }; // logits = bilinear x head_up of the head's low-resolution output
+              OP_UPLOGITS,   // logits = bilinear x head_up of the head's low-resolution output
+              // DeepLabV3+ (deeplab.hip)
+              OP_PARITY,     // up = 1: out [4N][H/2][W/2] = parity sub-grids of in [N][H][W] (dilation 2 -> plain 3x3); up = 0: the inverse
+              OP_DW,         // depthwise 3x3 (dilation = padding = up) of `in` into channels [oc0, oc0 + C) of `out`; weights param `dwp` at channel wc0
+              OP_GAP,        // out [N][1][1][C] = mean over the pixels of in (AdaptiveAvgPool2d(1))
+              OP_BCAST,      // out [N][H][W][C] = in [N][1][1][C] (bilinear resize of a 1x1 map)
+              OP_DROPE,      // out = in * element-wise dropout keep mask / (1 - p)
+              OP_UPB };      // out = bilinear x up of in (align_corners=True)
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -86,6 +93,8 @@ struct Op {
   int lane = 0;           // forward stream: 0 main, 1 side (decoder nodes that only need early encoder features)
   int gn = -1, up = 1;    // OP_GN
   int ins[4] = {-1, -1, -1, -1};   // OP_MERGE
+  int dwp = -1, oc0 = 0, wc0 = 0;  // OP_DW: weight parameter, first output channel, first weight channel
+  bool dw_first = true;            // OP_DW: first writer of the parameter's gradient slice? (all slices accumulate: atomics)
 };
 
 }  // namespace octseg
@@ -104,7 +113,8 @@ struct octseg_plan {
   size_t z4_off = 0, dz4_off = 0;
   // stem through thin.hip: frame and normalisation of the last training forward (its weight gradient gathers the frame again)
   const float* stem_image = nullptr; int stem_normalize = 0; float stem_mean[3] = {0, 0, 0}, stem_std[3] = {1, 1, 1};
-  const float* dropout_keep = nullptr;   // device [B][128] of {0, 1}: Dropout2d keep pattern of the next training forward (caller-owned)
+  const float* dropout_keep = nullptr;   // keep pattern of the next training forward (caller-owned device floats of {0, 1}): fpn [B][128]
+                                         // (Dropout2d), deeplabv3plus [B][H/16][W/16][256] NHWC (element-wise Dropout of ASPP.project)
   float dropout_p = 0.2f;
   size_t param_numel = 0, buffer_numel = 0;
   size_t ws_bytes = 0;

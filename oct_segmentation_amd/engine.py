@@ -16,8 +16,9 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus')
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
+_DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
 _ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152')
 
 
@@ -158,7 +159,10 @@ class SegNet(nn.Module):
                      'decoder_attention_type': None, 'activation': None, 'aux_params': None,
                      # smp.FPN's own keywords, at their defaults
                      'decoder_pyramid_channels': 256, 'decoder_segmentation_channels': 128, 'decoder_merge_policy': 'add',
-                     'decoder_dropout': 0.2, 'upsampling': 4}
+                     'decoder_dropout': 0.2, 'upsampling': 4,
+                     # smp.DeepLabV3Plus's own keywords, at their defaults (decoder_channels: see _ARCH_DEFAULTS)
+                     'encoder_output_stride': 16, 'decoder_atrous_rates': (12, 24, 36)}
+    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}}
 
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
                  device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
@@ -168,7 +172,7 @@ class SegNet(nn.Module):
         for k, v in kwargs.items():
             if k not in self._SMP_DEFAULTS:
                 raise TypeError(f'SegNet got an unexpected keyword argument {k!r}')
-            dflt = self._SMP_DEFAULTS[k]
+            dflt = self._ARCH_DEFAULTS.get(arch.lower(), {}).get(k, self._SMP_DEFAULTS[k])
             if (tuple(v) if isinstance(v, (list, tuple)) else v) != dflt:
                 raise NotImplementedError(f'{k}={v!r}: the gfx950 engine builds the smp default ({dflt!r}) only')
         a = arch.lower()
@@ -187,8 +191,10 @@ class SegNet(nn.Module):
         # train_step_raw as ONE replayed hipGraph per (B, H, W) plan (octseg_net_train_step + octseg_plan_set_train_graph): the ~800
         # launches of a step cost the host tens of milliseconds to enqueue, which bounds small per-GPU batches; not with `exchange`
         self.use_train_graph = use_train_graph
-        # arch 'fpn': nn.Dropout2d(0.2) sits behind the merge.  Training forwards draw a keep pattern [B, 128] on the device (torch's
-        # RNG, as the reference's Dropout2d does) unless `dropout_keep` holds one (tests inject the oracle's); eval ignores it.
+        # arch 'fpn': nn.Dropout2d(0.2) sits behind the merge; arch 'deeplabv3plus': nn.Dropout(0.5) behind ASPP.project.  Training
+        # forwards draw a keep pattern on the device (torch's RNG, as the reference's modules do) -- [B, 128] per channel for FPN,
+        # [B, H/16, W/16, 256] NHWC per element for DeepLabV3+ -- unless `dropout_keep` holds one (tests inject the oracle's;
+        # DeepLabV3+ also accepts torch's NCHW [B, 256, H/16, W/16]); eval ignores it.
         self.dropout_keep = None
         self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
         self._buffer_epoch = 0  # the same for bn_buffers (every train-mode forward)
@@ -385,6 +391,28 @@ class SegNet(nn.Module):
             raise ValueError(f'expected a float32 CUDA tensor [B,3,H,W], got {tuple(x.shape)} {x.dtype} {x.device}')
         return x.contiguous()
 
+    def _has_dropout(self):
+        return self.arch in ('fpn', 'deeplabv3plus')
+
+    def _keep_shape(self, B, H, W):
+        if self.arch == 'fpn':
+            return (B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT
+        return (B, H // 16, W // 16, _DLV3P_CHANNELS), 1.0 - _DLV3P_DROPOUT
+
+    def _draw_keep(self, B, H, W, device):
+        """The dropout keep pattern of one training forward, in the layout octseg_plan_set_dropout takes."""
+        shape, pkeep = self._keep_shape(B, H, W)
+        keep = self.dropout_keep
+        if keep is None:
+            return torch.bernoulli(torch.full(shape, pkeep, device=device))
+        keep = keep.to(device, torch.float32)
+        if self.arch == 'deeplabv3plus' and keep.dim() == 4 and tuple(keep.shape) == (shape[0], shape[3], shape[1], shape[2]):
+            keep = keep.permute(0, 2, 3, 1)      # torch's NCHW mask -> the engine's NHWC
+        keep = keep.contiguous()
+        if tuple(keep.shape) != shape:
+            raise ValueError(f'dropout_keep must be {list(shape)} of 0 / 1, got {tuple(keep.shape)}')
+        return keep
+
     def _graph_train_step(self, image, target, normalize, mean, std, grad_scale):
         """forward + Dice + backward through octseg_net_train_step with the plan's training graph on: inputs are copied into persistent
         buffers (a replay needs every pointer unchanged), the step runs on a capturable stream, outputs come back as copies."""
@@ -407,18 +435,15 @@ class SegNet(nn.Module):
                 logits=torch.empty((B, self.classes, H, W), dtype=torch.float32, device=dev),
                 loss=torch.empty((), dtype=torch.float32, device=dev),
                 stats=torch.empty((B, self.classes, 4), dtype=torch.int64, device=dev),
-                keep=torch.ones((B, _FPN_SEG_CHANNELS), dtype=torch.float32, device=dev),
+                keep=torch.ones(self._keep_shape(B, H, W)[0] if self._has_dropout() else (1,), dtype=torch.float32, device=dev),
                 stream=torch.cuda.Stream(device=dev))    # (the legacy default stream cannot be captured)
             L.check(L.lib().octseg_plan_set_train_graph(plan.handle, 1))
-            if self.arch == 'fpn':
+            if self._has_dropout():
                 L.check(L.lib().octseg_plan_set_dropout(plan.handle, L.ptr(io['keep'])))
         io['img'].copy_(x)
         io['mask'].copy_(target)
-        if self.arch == 'fpn':
-            keep = self.dropout_keep
-            if keep is None:
-                keep = torch.bernoulli(torch.full((B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT, device=x.device))
-            io['keep'].copy_(keep.to(x.device, torch.float32))
+        if self._has_dropout():
+            io['keep'].copy_(self._draw_keep(B, H, W, x.device))
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
         cur = torch.cuda.current_stream(x.device)
@@ -449,13 +474,8 @@ class SegNet(nn.Module):
             plan.seen_version = ver
         if not train:
             plan.seen_buffers = bver
-        if self.arch == 'fpn' and train:
-            keep = self.dropout_keep
-            if keep is None:
-                keep = torch.bernoulli(torch.full((B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT, device=x.device))
-            keep = keep.to(x.device, torch.float32).contiguous()
-            if tuple(keep.shape) != (B, _FPN_SEG_CHANNELS):
-                raise ValueError(f'dropout_keep must be [{B}, {_FPN_SEG_CHANNELS}] of 0 / 1, got {tuple(keep.shape)}')
+        if self._has_dropout() and train:
+            keep = self._draw_keep(B, H, W, x.device)
             plan.drop_keep = keep      # the backward of this step reads it too: keep it alive with the plan
             L.check(L.lib().octseg_plan_set_dropout(plan.handle, L.ptr(keep)))
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))

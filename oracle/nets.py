@@ -125,6 +125,24 @@ class ResNetEncoder(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
+    def make_dilated(self, output_stride):
+        """smp EncoderMixin.make_dilated (encoders/_base.py) + utils.replace_strides_with_dilation: output_stride 16 turns EVERY conv of
+        layer4 into stride 1 / dilation 2 / padding (k // 2) * 2 (the 1x1 convs and the downsample included), 8 also layer3 with 2 and
+        layer4 with 4."""
+        if output_stride == 16:
+            stages = [(self.layer4, 2)]
+        elif output_stride == 8:
+            stages = [(self.layer3, 2), (self.layer4, 4)]
+        else:
+            raise ValueError(f'Output stride should be 16 or 8, got {output_stride}.')
+        for stage, rate in stages:
+            for m in stage.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.stride = (1, 1)
+                    m.dilation = (rate, rate)
+                    kh, kw = m.kernel_size
+                    m.padding = ((kh // 2) * rate, (kw // 2) * rate)
+
     def forward(self, x):
         f0 = x
         f1 = self.relu(self.bn1(self.conv1(x)))
@@ -343,6 +361,97 @@ class FPNDecoder(nn.Module):
         return self.dropout(sum(pyramid))       # MergeBlock('add')
 
 
+class InjectableDropout(nn.Module):
+    """nn.Dropout(p) (element-wise) whose keep pattern can be supplied: ``mask`` of the input's shape, {0, 1}; kept elements are scaled by
+    1 / (1 - p) as torch does.  With no mask set it IS nn.functional.dropout."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+        self.mask = None
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        if self.mask is None:
+            return F.dropout(x, self.p, True)
+        return x * (self.mask.to(x.dtype) / (1.0 - self.p))
+
+
+class SeparableConv2d(nn.Sequential):
+    """smp base/modules.py SeparableConv2d: depthwise conv (groups = channels, no bias) then pointwise 1x1; nothing in between."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__(
+            nn.Conv2d(cin, cin, kernel_size, stride=stride, padding=padding, dilation=dilation, groups=cin, bias=False),
+            nn.Conv2d(cin, cout, kernel_size=1, bias=bias),
+        )
+
+
+class ASPPSeparableConv(nn.Sequential):
+    def __init__(self, cin, cout, dilation):
+        super().__init__(SeparableConv2d(cin, cout, 3, padding=dilation, dilation=dilation, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class ASPPPooling(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        for mod in self:
+            x = mod(x)
+        return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+
+
+class ASPP(nn.Module):
+    """smp decoders/deeplabv3/decoder.py ASPP(separable=True): 1x1, three separable dilated 3x3, image pooling; concat; 1x1 project +
+    BN + ReLU + Dropout(0.5) (element-wise)."""
+
+    def __init__(self, cin, cout, atrous_rates):
+        super().__init__()
+        mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())]
+        for r in atrous_rates:
+            mods.append(ASPPSeparableConv(cin, cout, r))
+        mods.append(ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(), InjectableDropout(0.5))
+
+    def forward(self, x):
+        return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+
+
+class DeepLabV3PlusDecoder(nn.Module):
+    """smp decoders/deeplabv3/decoder.py DeepLabV3PlusDecoder (output_stride 16): ASPP on the stride-16 feature, separable 3x3, bilinear
+    x4 (align_corners=True), concat with a 48-channel 1x1 projection of the stride-4 feature, separable 3x3."""
+
+    def __init__(self, encoder_channels, out_channels=256, atrous_rates=(12, 24, 36), output_stride=16):
+        super().__init__()
+        if output_stride not in (8, 16):
+            raise ValueError(f'Output stride should be 8 or 16, got {output_stride}.')
+        self.out_channels = out_channels
+        self.aspp = nn.Sequential(
+            ASPP(encoder_channels[-1], out_channels, atrous_rates),
+            SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(),
+        )
+        self.up = nn.UpsamplingBilinear2d(scale_factor=2 if output_stride == 8 else 4)
+        hi_in, hi_out = encoder_channels[-4], 48
+        self.block1 = nn.Sequential(nn.Conv2d(hi_in, hi_out, 1, bias=False), nn.BatchNorm2d(hi_out), nn.ReLU())
+        self.block2 = nn.Sequential(SeparableConv2d(hi_out + out_channels, out_channels, 3, padding=1, bias=False),
+                                    nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    @property
+    def dropout(self):
+        return self.aspp[0].project[3]
+
+    def forward(self, *features):
+        a = self.up(self.aspp(features[-1]))
+        hi = self.block1(features[-4])
+        return self.block2(torch.cat([a, hi], dim=1))
+
+
 class SegmentationHead(nn.Sequential):
     def __init__(self, cin, cout, kernel_size, upsampling=1):
         super().__init__(
@@ -388,6 +497,11 @@ class SegmentationModel(nn.Module):
         elif arch == 'fpn':
             self.decoder = FPNDecoder(ch)
             self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 1, upsampling=4)
+        elif arch == 'deeplabv3plus':
+            # smp DeepLabV3Plus defaults: encoder_output_stride=16, decoder_channels=256, decoder_atrous_rates=(12, 24, 36), upsampling=4
+            self.encoder.make_dilated(16)
+            self.decoder = DeepLabV3PlusDecoder(ch)
+            self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 1, upsampling=4)
         else:
             raise KeyError(arch)
         _init_decoder(self.decoder)
@@ -402,7 +516,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):

@@ -1,0 +1,192 @@
+"""DeepLabV3+ over the ResNet encoders on the engine: `DeepLabV3Plus` is one of the architectures the reference
+sweeps (configs/tune.yaml:9-18 -> smp.create_model(arch, ...), src/models/smp/model.py:38-44; DeepLabV3Plus/resnet101 is a per-class
+winner in eval/tuning/configs_best.xlsx).  Oracle: oracle/nets.py DeepLabV3PlusDecoder + ResNetEncoder.make_dilated (smp 0.3.3
+restated: layer4 at stride 1 / dilation 2, ASPP = 1x1 + three separable dilated 3x3 (12, 24, 36) + image pooling, 1x1 project + BN +
+ReLU + Dropout(0.5), separable 3x3, bilinear x4 align_corners, 48-channel 1x1 on the stride-4 feature, separable 3x3 on the concat, 1x1 head +
+UpsamplingBilinear2d(4)).  The element-wise dropout's keep pattern is injected on both sides.  The engine runs the dilated layer4 as
+plain convolutions on the four parity sub-grids (deeplab.hip), so this file is also the test of that identity.
+Tolerances as for the other nets (test_gpu_net.py)."""
+import numpy as np
+import pytest
+import torch
+
+from synth import make_batch
+
+pytestmark = pytest.mark.gpu
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _oracle_dl(enc, classes, seed, kinkfree):
+    from test_gpu_net import _oracle
+    m = _oracle('deeplabv3plus', enc, classes, seed=seed, kinkfree=kinkfree)
+    if kinkfree:   # BatchNorm outputs of ~8 in front of the head: keep |logits| of order 1 (a saturated sigmoid has no gradient)
+        with torch.no_grad():
+            m.segmentation_head[0].weight.mul_(0.03)
+    return m
+
+
+def _pair(cuda, enc, classes, B, H, W, seed, kinkfree, dtype=torch.float32):
+    from oct_segmentation_amd.engine import SegNet
+    from oracle import DiceLoss
+    ref = _oracle_dl(enc, classes, seed, kinkfree)
+    net = SegNet('deeplabv3plus', enc, classes=classes, device=cuda, compute_dtype=dtype)
+    assert sorted(net.state_dict().keys()) == sorted(ref.state_dict().keys())       # smp's module tree, key for key
+    net.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(seed + 11)
+    img, mask = make_batch(B, classes, max(H, W), seed=seed, empty_last=(classes > 1))
+    img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
+    # the pooled ASPP branch normalises B values per channel: frames with the same statistics give B nearly equal values there, and
+    # BatchNorm of nearly equal values amplifies fp32 rounding without bound (d / sqrt(d^2 + eps)).  Give every frame its own brightness.
+    img = (img * (0.35 + 0.65 * torch.arange(B).view(B, 1, 1, 1) / max(1, B - 1))).round().contiguous()
+    keep = (torch.rand(B, 256, H // 16, W // 16, generator=g) < 0.5).float()      # torch's layout (NCHW); the engine takes it as is
+    ref.train(); net.train()
+    ref.decoder.dropout.mask = keep
+    net.dropout_keep = keep
+    mean = torch.tensor(MEAN).view(1, 3, 1, 1); std = torch.tensor(STD).view(1, 3, 1, 1)
+    z = ref((img - mean) / std)
+    loss_ref = DiceLoss()(z, mask)
+    loss_ref.backward()
+    loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True, mean=MEAN, std=STD)
+    torch.cuda.synchronize()
+    return ref, net, img, mask, z.detach(), loss_ref, logits.cpu(), loss, stats
+
+
+def test_deeplab_param_counts():
+    """smp's DeepLabV3Plus sizes (CPU part of the test: the oracle's module tree)."""
+    from oracle.nets import create_model
+    assert sum(p.numel() for p in create_model('deeplabv3plus', 'resnet18').parameters()) == 12_329_297
+    assert sum(p.numel() for p in create_model('deeplabv3plus', 'resnet50').parameters()) == 26_677_585
+
+
+@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 1, 2, 64, 96), ('resnet34', 3, 2, 128, 64), ('resnet50', 2, 4, 128, 128)])
+def test_deeplab_train_step_parity_fp32(cuda, enc, classes, B, H, W):
+    from oracle import get_stats
+    from test_gpu_net import _grad_report
+    ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, enc, classes, B, H, W, seed=3, kinkfree=False)
+    scale = z.abs().max().item()
+    err = (logits - z).abs().max().item()
+    cos, worst, name = _grad_report(net.named_grads(), ref)
+    print(f'deeplabv3plus/{enc} {classes}c B{B} {H}x{W}: logits {err:.2e} / {scale:.2f}, loss {abs(loss.item() - loss_ref.item()):.1e}, grad cosine {cos:.8f} worst {worst:.1e} ({name})')
+    assert err <= (2e-4 if enc == 'resnet50' else 1e-4) * max(1.0, scale)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    away = (z.abs() > 1e-3)
+    assert torch.equal((logits > 0)[away], (z > 0)[away])
+    tp, fp, fn, tn = get_stats((logits.sigmoid() > 0.5).long(), mask.long())
+    assert torch.equal(stats.cpu(), torch.stack([tp, fp, fn, tn], dim=-1))
+    assert cos >= (0.998 if enc == 'resnet50' else 0.999)      # ReLU-kink flips (random BatchNorm parameters); the kink-free test below is exact
+    # BatchNorm running statistics (the pooled branch's BatchNorm sees B values per channel: unbiased variance over the batch)
+    sd, rd = net.state_dict(), ref.state_dict()
+    for k in rd:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            d = (sd[k].cpu() - rd[k]).abs().max().item()
+            assert d <= 1e-4 * max(1.0, rd[k].abs().max().item()), (k, d)
+
+
+@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet50', 1, 4, 96, 64)])
+def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
+    """BatchNorm biases at +-8 (no pre-activation near the ReLU kink): every parameter gradient -- depthwise kernels, pointwise convs, the
+    pooled branch, the dilated layer4 through the parity re-arrangement, the whole encoder -- within 2e-3 of its largest element.
+    (B = 4: with two frames the pooled branch's BatchNorm sees x_hat = +-1 exactly and its input gradient is a difference of equal terms --
+    analytically ~0, numerically noise in torch and here alike.)"""
+    import copy
+    from oracle import DiceLoss
+    from test_gpu_net import _grad_report
+    ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, enc, classes, B, H, W, seed=5, kinkfree=True)
+    grads = net.named_grads()
+    cos, worst, name = _grad_report(grads, ref)
+    err = (logits - z).abs().max().item()
+    print(f'deeplabv3plus/{enc} kink-free: logits {err:.2e} / {z.abs().max().item():.2f}, grad cosine {cos:.9f}, worst {worst:.2e} ({name})')
+    assert err <= 1e-4 * max(1.0, z.abs().max().item())
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert cos >= 0.999999
+    # per parameter: 2e-3 of its largest element; a parameter that misses it is re-judged against a float64 run of the oracle (the fuzz
+    # test's criterion: at most 4x as far from the exact gradient as torch's own fp32 is).  What needs it here: the 1x1 conv of the pooled
+    # ASPP branch sits in front of a BatchNorm over B values per channel, whose input gradient g - mean(g) - x_hat mean(g x_hat) cancels
+    # all but B - 2 degrees of freedom -- a small remainder of large terms in torch's fp32 as much as here -- and that noise then travels
+    # through the image pooling's gradient into every encoder layer.
+    gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
+    rel = {n: (grads[n].cpu() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax) for n, p in ref.named_parameters()}
+    loose = sorted(n for n, e in rel.items() if e >= 2e-3)
+    if loose:
+        ref64 = copy.deepcopy(ref).double()
+        ref64.zero_grad()
+        ref64.decoder.dropout.mask = ref.decoder.dropout.mask.double()
+        mean = torch.tensor(MEAN).view(1, 3, 1, 1).double(); std = torch.tensor(STD).view(1, 3, 1, 1).double()
+        DiceLoss()(ref64((img.double() - mean) / std), mask.double()).backward()
+        p64, p32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
+        ratios = []
+        for n in loose:
+            exact = p64[n].grad
+            e_eng = (grads[n].cpu().double() - exact).abs().max().item()
+            e_ora = (p32[n].grad.double() - exact).abs().max().item()
+            ratios.append((e_eng / max(e_ora, 1e-30), n, e_eng, e_ora))
+        ratios.sort(reverse=True)
+        print(f'  {len(loose)} parameters re-judged against float64; worst engine/oracle error ratio {ratios[0][0]:.2f} ({ratios[0][1]}: {ratios[0][2]:.2e} vs {ratios[0][3]:.2e})')
+        for r, n, e_eng, e_ora in ratios:
+            assert e_eng <= max(4.0 * e_ora, 2e-3 * max(p64[n].grad.abs().max().item(), 1e-3 * gmax)), (n, e_eng, e_ora)
+
+
+def test_deeplab_eval_forward_and_batch_of_one(cuda):
+    """Eval: dropout is the identity, BatchNorm uses running statistics: logits equal the oracle's eval forward -- also for a batch of one.
+    Training a batch of one raises torch's own error (the pooled branch's BatchNorm has one value per channel).  Training without an
+    injected pattern draws one: two steps differ, both finite."""
+    from oct_segmentation_amd.engine import SegNet
+    ref = _oracle_dl('resnet18', 2, seed=9, kinkfree=False).eval()
+    net = SegNet('deeplabv3plus', 'resnet18', classes=2, device=cuda, compute_dtype=torch.float32).eval()
+    net.load_state_dict(ref.state_dict())
+    img, mask = make_batch(2, 2, 96, seed=4)
+    with torch.no_grad():
+        z = ref(img)
+        z1 = ref(img[:1])
+    y = net(img.to(cuda)).cpu()
+    assert (y - z).abs().max().item() <= 1e-4 * max(1.0, z.abs().max().item())
+    y1 = net(img[:1].to(cuda)).cpu()
+    assert (y1 - z1).abs().max().item() <= 1e-4 * max(1.0, z1.abs().max().item())
+    net.train()
+    with pytest.raises(ValueError, match='Expected more than 1 value per channel'):
+        net.train_step_raw(img[:1].to(cuda), mask[:1].to(cuda))
+    torch.manual_seed(1)
+    l1, _, _ = net.train_step_raw(img.to(cuda), mask.to(cuda))
+    l2, _, _ = net.train_step_raw(img.to(cuda), mask.to(cuda))
+    assert np.isfinite(l1.item()) and np.isfinite(l2.item()) and l1.item() != l2.item()
+    assert torch.isfinite(net.arena.grad).all()
+
+
+def test_deeplab_bf16_704_properties(cuda):
+    """BASELINE frame size in bf16 (DeepLabV3+ / resnet50, B = 4): finite, eval forward deterministic and permutation-equivariant, counts
+    recounted from the logits, gradient linear in grad_scale; against the fp32 oracle at 256^2: Dice within 1e-3; f16 eval finite."""
+    from oct_segmentation_amd.engine import SegNet
+    from oracle import DiceLoss
+    net = SegNet('deeplabv3plus', 'resnet50', classes=1, device=cuda, compute_dtype=torch.bfloat16, seed=3)
+    img, mask = (t.to(cuda) for t in make_batch(4, 1, 704, seed=21))
+    net.eval()
+    y1 = net(img)
+    assert torch.isfinite(y1).all() and torch.equal(y1, net(img))
+    perm = torch.tensor([2, 0, 3, 1], device=cuda)
+    assert torch.equal(net(img[perm]), y1[perm])
+    net.train()
+    net.dropout_keep = (torch.rand(4, 44, 44, 256, generator=torch.Generator().manual_seed(2)) < 0.5).float()
+    loss, logits, stats = net.train_step_raw(img, mask, grad_scale=1.0)
+    g1 = net.arena.grad.clone()
+    s = stats.cpu()
+    assert int(s[..., 0].sum()) == int(((logits > 0) & (mask > 0)).sum()) and torch.equal(s.sum(-1), torch.full_like(s[..., 0], 704 * 704))
+    loss2, _, _ = net.train_step_raw(img, mask, grad_scale=0.5)
+    assert abs(loss2.item() - loss.item()) < 1e-6
+    ratio = (net.arena.grad.norm() / g1.norm()).item()
+    assert abs(ratio - 0.5) < 2e-2
+    ref = _oracle_dl('resnet50', 1, seed=13, kinkfree=True).train()
+    net2 = SegNet('deeplabv3plus', 'resnet50', classes=1, device=cuda, compute_dtype=torch.bfloat16)
+    net2.load_state_dict(ref.state_dict())
+    net2.train()
+    im, mk = make_batch(4, 1, 256, seed=17)
+    keep = (torch.rand(4, 256, 16, 16, generator=torch.Generator().manual_seed(3)) < 0.5).float()
+    ref.decoder.dropout.mask = keep
+    net2.dropout_keep = keep
+    z = ref(im)
+    loss_ref = DiceLoss()(z, mk)
+    loss_b, logits_b, _ = net2.train_step_raw(im.to(cuda), mk.to(cuda))
+    print(f'deeplabv3plus/resnet50 bf16 256^2: Dice loss {loss_b.item():.6f} vs {loss_ref.item():.6f}, logits {(logits_b.cpu() - z.detach()).abs().max().item():.2e} / {z.detach().abs().max().item():.1f}')
+    assert abs(loss_b.item() - loss_ref.item()) <= 1e-3
+    half = SegNet('deeplabv3plus', 'resnet50', classes=1, device=cuda, compute_dtype=torch.float16).eval()
+    half.load_state_dict(net2.state_dict())
+    assert torch.isfinite(half(im.to(cuda), normalize=True, mean=MEAN, std=STD)).all()

@@ -52,6 +52,12 @@ CASES = [
     (3, 40, 72, 32, 32, 1, 1, 0, False),
     (2, 48, 64, 16, 16, 4, 2, 1, True),      # ConvTranspose2d 16 -> 16: four 2x2-tap launches writing at stride 2
     (1, 64, 80, 32, 32, 4, 2, 1, True),
+    # DeepLabV3+ shapes: the pooled ASPP branch is a 1x1 conv on a 1x1 map (M = batch pixels), the separable convs' pointwise halves
+    # contract over 304 channels (4.75 K steps) and the high-resolution branch has 48 output channels
+    (2, 1, 1, 512, 256, 1, 1, 0, False),
+    (4, 1, 1, 2048, 256, 1, 1, 0, False),
+    (2, 16, 24, 304, 256, 1, 1, 0, False),
+    (2, 16, 24, 256, 48, 1, 1, 0, False),
 ]
 
 

@@ -40,8 +40,9 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
   void* wsp = carve(ws);
   float* image = (float*)carve(px * 3 * 4); float* logits = (float*)carve(px * d.classes * 4); float* target = (float*)carve(px * d.classes * 4);
   float* loss = (float*)carve(4); long long* stats = (long long*)carve((size_t)d.batch * d.classes * 4 * 8);
-  float* keep = (float*)carve((size_t)d.batch * 128 * 4);
-  octseg_plan_set_dropout(p, keep);                 // (arch fpn: Dropout2d keep pattern; ignored by the others)
+  const bool dl = !strcmp(d.arch, "deeplabv3plus");   // fpn: Dropout2d pattern [B][128]; deeplabv3plus: element-wise [B][H/16][W/16][256]
+  float* keep = (float*)carve(dl ? (size_t)d.batch * (d.height / 16) * (d.width / 16) * 256 * 4 : (size_t)d.batch * 128 * 4);
+  octseg_plan_set_dropout(p, keep);                 // (ignored by the other architectures)
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   void* st = (void*)(uintptr_t)0x4000; void* comm = (void*)(uintptr_t)0x4100;
   const unsigned long long l0 = dry_launches();
@@ -81,7 +82,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 }  // namespace
 
 int main() {
-  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn"};
+  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus"};
   const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
