@@ -6,7 +6,8 @@
  *
  *   octseg_plan_create / _destroy      smp.create_model(arch, encoder_name, in_channels, classes)
  *                                      src/models/smp/model.py:38-44
- *   octseg_plan_set_dropout            the nn.Dropout2d inside smp's FPN decoder (arch "fpn"): its keep pattern, injected
+ *   octseg_plan_set_dropout            the nn.Dropout2d inside smp's FPN decoder (arch "fpn") / the nn.Dropout of DeepLabV3+'s
+ *                                      ASPP.project (arch "deeplabv3plus"): its keep pattern, injected
  *   octseg_plan_param_info / bn_info   the nn.Module parameter / buffer tree behind state_dict()
  *                                      (load_from_checkpoint, src/predict.py:39-48)
  *   octseg_net_forward                 OCTSegmentationModel.forward (normalize=1, model.py:65-71) and
@@ -60,7 +61,7 @@ typedef enum {
 typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
-  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" (case-insensitive) */
+  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" (case-insensitive) */
   const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
   int classes;          /* output channels */
   int batch, height, width;
@@ -123,6 +124,10 @@ int octseg_plan_params_changed(octseg_plan* plan);
 /* arch "fpn" (smp FPN, one of the reference's sweep architectures: configs/tune.yaml:9-18 through smp.create_model, model.py:38-44):
  * the Dropout2d(0.2) behind the merge needs a keep pattern in training -- device float [batch][128] of 0 / 1, caller-owned, read by the
  * next training forward AND its backward (kept channels are scaled by 1 / (1 - 0.2), torch's Dropout2d).  Eval forwards ignore it. */
+/* arch "deeplabv3plus" (smp DeepLabV3Plus at its defaults: encoder_output_stride 16, decoder_channels 256, atrous rates (12, 24, 36);
+ * same sweep, same call): the keep pattern is per ELEMENT of ASPP.project's output -- device float [batch][H/16][W/16][256] (NHWC) of
+ * 0 / 1, kept elements scaled by 1 / (1 - 0.5).  A training forward with batch 1 fails like torch does ("Expected more than 1 value per
+ * channel when training": the pooled ASPP branch's BatchNorm). */
 int octseg_plan_set_dropout(octseg_plan* plan, const float* keep_dev);
 
 /* Serving path (reference: src/models/smp/predict.py segment(), model.py:183-200 predict()): enable = 1 makes every

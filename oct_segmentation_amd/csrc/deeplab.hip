@@ -116,14 +116,17 @@ hipError_t launch_dw_conv(int dtype, const void* in, int inC, int ic0, void* out
 }
 
 // weight gradient: dw[t][wc0 + c] += sum_{n, y, x} gout[n][y][x][oc0 + c] * in[n][y + d (r - 1)][x + d (s - 1)][ic0 + c].
-// Block (bx, by): channel vectors [256 by, 256 by + nv), thread (r, v) owns vector v of the pixels r, r + rows, ... of its share; nine
-// taps x VEC sums in registers, folded over the rows through LDS one tap at a time, one atomic per block and weight.
+// Block (bx, by): channel vectors [DW_CH by, DW_CH by + nv), thread (r, v) owns vector v of the pixels r, r + rows, ... of its share; nine
+// taps x VEC sums in registers, folded over the rows through LDS one tap at a time, one atomic per block and weight.  The atomics
+// number (pixel groups) x 9 x C whatever the channel split, so the grid gets its width from 32-vector channel chunks (>= 8 pixel rows
+// per block) and about 1024 blocks in all (first version: 256-vector chunks x 256 pixel groups, one pixel row per block: 0.5 ms per launch).
+constexpr int DW_CH = 32;   // channel vectors per block of the reductions below
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwArgs a, float* dw) {
   constexpr int VEC = EV<T>::VEC;
   __shared__ float red[256 * VEC];
   const int vpc = a.C / VEC, ivs = a.inC / VEC, ovs = a.outC / VEC, iv0 = a.ic0 / VEC, ov0 = a.oc0 / VEC;
-  const int v0 = blockIdx.y * 256, nv = min(256, vpc - v0), rows = 256 / nv;
+  const int v0 = blockIdx.y * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
   const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
   float acc[9][VEC];
 #pragma unroll
@@ -167,12 +170,14 @@ hipError_t launch_dw_wgrad(int dtype, const void* in, int inC, int ic0, const vo
   DwArgs a{in, const_cast<void*>(gout), nullptr, inC, ic0, goC, oc0, wC, wc0, N, H, W, C, dil, 0, 0};
   if (!dw_ok(dtype, a)) return hipErrorInvalidValue;
   const int vpc = C / (dtype == DT_F32 ? 4 : 8);
-  const int nv = vpc < 256 ? vpc : 256, rows = 256 / nv;
+  const int nv = vpc < DW_CH ? vpc : DW_CH, rows = 256 / nv;
   const size_t npix = (size_t)N * H * W;
-  size_t gx = (npix + (size_t)rows * 64 - 1) / ((size_t)rows * 64);
-  if (gx > 256) gx = 256;
+  const int nch = (vpc + DW_CH - 1) / DW_CH;
+  size_t gx = (npix + (size_t)rows * 8 - 1) / ((size_t)rows * 8);      // >= 8 pixels per thread ...
+  const size_t want = (size_t)(1024 + nch - 1) / nch;                   // ... and about 1024 blocks in all (four per CU)
+  if (gx > want) gx = want;
   if (gx < 1 || deterministic_mode()) gx = 1;
-  const dim3 grid((unsigned)gx, (unsigned)((vpc + 255) / 256));
+  const dim3 grid((unsigned)gx, (unsigned)nch);
   if (dtype == DT_F32) hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, a, dw);
   else hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, a, dw);
   return hipGetLastError();
@@ -180,12 +185,12 @@ hipError_t launch_dw_wgrad(int dtype, const void* in, int inC, int ic0, const vo
 
 // ------------------------------------------------------------------ per-image channel sums and their broadcast
 // out[n][c] = sum_p in[n][p][c] / div   (AdaptiveAvgPool2d(1): div = HW; gradient of the broadcast below: div = 1).
-// grid (ceil(vpc / 256), N): deterministic (one block per image and channel chunk, fixed order).
+// grid (ceil(vpc / DW_CH), N): deterministic (one block per image and 32-vector channel chunk, >= 8 pixel rows each, fixed order).
 template <typename T>
 __global__ __launch_bounds__(256) void image_sum_kernel(const void* in, void* out, int HW, int vpc, float div) {
   constexpr int VEC = EV<T>::VEC;
   __shared__ float red[256 * VEC];
-  const int v0 = blockIdx.x * 256, nv = min(256, vpc - v0), rows = 256 / nv;
+  const int v0 = blockIdx.x * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
   const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
   const size_t n = blockIdx.y;
   float s[VEC];
@@ -215,7 +220,7 @@ hipError_t launch_image_sum(int dtype, const void* in, void* out, int N, int HW,
   const int vec = dtype == DT_F32 ? 4 : 8;
   if (C % vec != 0) return hipErrorInvalidValue;
   const int vpc = C / vec;
-  DL_DISPATCH(image_sum_kernel, dim3((vpc + 255) / 256, N), in, out, HW, vpc, div);
+  DL_DISPATCH(image_sum_kernel, dim3((vpc + DW_CH - 1) / DW_CH, N), in, out, HW, vpc, div);
   return hipGetLastError();
 }
 // out[n][p][c] (+)= scale * in[n][c]   (F.interpolate of a 1x1 map to any size, either align_corners: a broadcast; gradient of the mean)
