@@ -985,7 +985,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         const float* beta = E.params + P->params[b.beta].off;
         rc = need(lane, tseq[b.y]);   // same lane as its conv by construction; kept for safety
         if (rc) return rc;
-        if (E.train && b.count <= (double)BN_SMALL_COUNT)   // a handful of values per channel (pooled ASPP branch): exact two-pass statistics
+        if (E.train && b.count <= (double)BN_SMALL_COUNT)   // small tensors (pooled ASPP branch, 2x2 .. 16x16 maps): exact two-pass statistics
           HIPCHK(launch_bn_finalize_small(P->dtype, E.act(b.y), (int)b.count, b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f,
                                           1e-5f, E.bn_scale(op.bn), E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), st));
         else if (E.train)

@@ -82,14 +82,47 @@ def test_deeplab_train_step_parity_fp32(cuda, enc, classes, B, H, W):
             assert d <= 1e-4 * max(1.0, rd[k].abs().max().item()), (k, d)
 
 
+def judge_gradients(ref, grads, img, mask, tag=''):
+    """Per parameter: within 2e-3 of its largest element; a parameter that misses it is re-judged against a float64 run of the oracle (the
+    fuzz test's criterion: at most 4x as far from the exact gradient as torch's own fp32 is).  What needs it: the 1x1 conv of DeepLabV3+'s
+    pooled ASPP branch sits in front of a BatchNorm over B values per channel, whose input gradient g - mean(g) - x_hat mean(g x_hat)
+    cancels all but B - 2 degrees of freedom -- a small remainder of large terms in torch's fp32 as much as here.  The last term of the
+    bound is an absolute floor of ~40 fp32 roundings of the LARGEST gradient in the net: torch's CPU BatchNorm backward accumulates in
+    double (acc_type), so on 2x2 maps its fp32 run sits closer to float64 than any fp32 GPU implementation can.  Returns the number of
+    re-judged parameters."""
+    import copy
+    from oracle import DiceLoss
+    gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
+    rel = {n: (grads[n].cpu() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax) for n, p in ref.named_parameters()}
+    loose = sorted(n for n, e in rel.items() if e >= 2e-3)
+    if not loose:
+        return 0
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    if ref.decoder.dropout.mask is not None:
+        ref64.decoder.dropout.mask = ref.decoder.dropout.mask.double()
+    mean = torch.tensor(MEAN).view(1, 3, 1, 1).double(); std = torch.tensor(STD).view(1, 3, 1, 1).double()
+    DiceLoss()(ref64((img.double() - mean) / std), mask.double()).backward()
+    p64, p32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
+    ratios = []
+    for n in loose:
+        exact = p64[n].grad
+        e_eng = (grads[n].cpu().double() - exact).abs().max().item()
+        e_ora = (p32[n].grad.double() - exact).abs().max().item()
+        ratios.append((e_eng / max(e_ora, 1e-30), n, e_eng, e_ora))
+    ratios.sort(reverse=True)
+    print(f'  {tag}{len(loose)} parameters re-judged against float64; worst engine/oracle error ratio {ratios[0][0]:.2f} ({ratios[0][1]}: {ratios[0][2]:.2e} vs {ratios[0][3]:.2e})')
+    for r, n, e_eng, e_ora in ratios:
+        assert e_eng <= max(4.0 * e_ora, 2e-3 * max(p64[n].grad.abs().max().item(), 1e-3 * gmax), 5e-6 * gmax), (n, e_eng, e_ora)
+    return len(loose)
+
+
 @pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet50', 1, 4, 96, 64)])
 def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     """BatchNorm biases at +-8 (no pre-activation near the ReLU kink): every parameter gradient -- depthwise kernels, pointwise convs, the
     pooled branch, the dilated layer4 through the parity re-arrangement, the whole encoder -- within 2e-3 of its largest element.
     (B = 4: with two frames the pooled branch's BatchNorm sees x_hat = +-1 exactly and its input gradient is a difference of equal terms --
     analytically ~0, numerically noise in torch and here alike.)"""
-    import copy
-    from oracle import DiceLoss
     from test_gpu_net import _grad_report
     ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, enc, classes, B, H, W, seed=5, kinkfree=True)
     grads = net.named_grads()
@@ -99,31 +132,7 @@ def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     assert err <= 1e-4 * max(1.0, z.abs().max().item())
     assert abs(loss.item() - loss_ref.item()) <= 1e-5
     assert cos >= 0.999999
-    # per parameter: 2e-3 of its largest element; a parameter that misses it is re-judged against a float64 run of the oracle (the fuzz
-    # test's criterion: at most 4x as far from the exact gradient as torch's own fp32 is).  What needs it here: the 1x1 conv of the pooled
-    # ASPP branch sits in front of a BatchNorm over B values per channel, whose input gradient g - mean(g) - x_hat mean(g x_hat) cancels
-    # all but B - 2 degrees of freedom -- a small remainder of large terms in torch's fp32 as much as here -- and that noise then travels
-    # through the image pooling's gradient into every encoder layer.
-    gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
-    rel = {n: (grads[n].cpu() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax) for n, p in ref.named_parameters()}
-    loose = sorted(n for n, e in rel.items() if e >= 2e-3)
-    if loose:
-        ref64 = copy.deepcopy(ref).double()
-        ref64.zero_grad()
-        ref64.decoder.dropout.mask = ref.decoder.dropout.mask.double()
-        mean = torch.tensor(MEAN).view(1, 3, 1, 1).double(); std = torch.tensor(STD).view(1, 3, 1, 1).double()
-        DiceLoss()(ref64((img.double() - mean) / std), mask.double()).backward()
-        p64, p32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
-        ratios = []
-        for n in loose:
-            exact = p64[n].grad
-            e_eng = (grads[n].cpu().double() - exact).abs().max().item()
-            e_ora = (p32[n].grad.double() - exact).abs().max().item()
-            ratios.append((e_eng / max(e_ora, 1e-30), n, e_eng, e_ora))
-        ratios.sort(reverse=True)
-        print(f'  {len(loose)} parameters re-judged against float64; worst engine/oracle error ratio {ratios[0][0]:.2f} ({ratios[0][1]}: {ratios[0][2]:.2e} vs {ratios[0][3]:.2e})')
-        for r, n, e_eng, e_ora in ratios:
-            assert e_eng <= max(4.0 * e_ora, 2e-3 * max(p64[n].grad.abs().max().item(), 1e-3 * gmax)), (n, e_eng, e_ora)
+    assert judge_gradients(ref, grads, img, mask) <= 1
 
 
 def test_deeplab_eval_forward_and_batch_of_one(cuda):

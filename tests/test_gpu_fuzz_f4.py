@@ -1,0 +1,49 @@
+"""Seeded fuzz over the sweep architectures added in round 3 (FPN, DeepLabV3+): random encoder x batch x classes x
+non-square frame, kink-free normalisation biases (so that fp32 implementations agree on every ReLU mask), the oracle's dropout pattern
+injected.  Bounds of the per-architecture tests: logits 1e-4 of their scale (2e-4 behind the 50+-layer encoders), Dice 1e-5, counts exact,
+gradient cosine 1 - 1e-6, every parameter within 2e-3 of its largest element or re-judged against float64 (test_gpu_deeplab.judge_gradients).
+The existing 40-case fuzz (test_gpu_fuzz.py) keeps its three architectures so that its seeded sequence stays the one of round 1."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n=10, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        arch = ['fpn', 'deeplabv3plus'][k % 2]
+        enc = ['resnet18', 'resnet34', 'resnet50', 'resnet101'][rng.integers(4)]
+        B = int(rng.integers(2, 5)) if arch == 'fpn' else int(rng.integers(3, 5))
+        classes = int(rng.integers(1, 4))
+        H, W = (int(32 * rng.integers(2, 5)) for _ in range(2))
+        out.append((k, arch, enc, B, classes, H, W))
+    return out
+
+
+@pytest.mark.parametrize('case', _cases(), ids=lambda c: f'{c[0]}-{c[1]}-{c[2]}-B{c[3]}-C{c[4]}-{c[5]}x{c[6]}')
+def test_fuzz_f4_fp32(cuda, case):
+    from oracle import get_stats
+    from test_gpu_net import _grad_report
+    import test_gpu_deeplab, test_gpu_fpn
+    k, arch, enc, B, classes, H, W = case
+    pair = test_gpu_fpn._pair if arch == 'fpn' else test_gpu_deeplab._pair
+    ref, net, img, mask, z, loss_ref, logits, loss, stats = pair(cuda, enc, classes, B, H, W, seed=100 + k, kinkfree=True)
+    scale = z.abs().max().item()
+    err = (logits - z).abs().max().item()
+    grads = net.named_grads()
+    cos, worst, name = _grad_report(grads, ref)
+    print(f'k={k} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.2f} loss {abs(loss.item() - loss_ref.item()):.1e} cos {cos:.9f} worst {worst:.1e} ({name})')
+    assert err <= (2e-4 if enc in ('resnet50', 'resnet101') else 1e-4) * max(1.0, scale)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    tp, fp, fn, tn = get_stats((logits.sigmoid() > 0.5).long(), mask.long())
+    away = z.abs() > 1e-3
+    if bool(away.all()):
+        assert torch.equal(stats.cpu(), torch.stack([tp, fp, fn, tn], dim=-1))
+    assert cos >= 0.999999
+    if arch == 'fpn':     # (FPN's own frames: test_gpu_fpn._pair does not rescale them, judge_gradients needs the frame the oracle saw)
+        assert worst < 2e-3 or test_gpu_deeplab.judge_gradients(ref, grads, img, mask, tag=f'k={k} ') <= 2
+    else:
+        test_gpu_deeplab.judge_gradients(ref, grads, img, mask, tag=f'k={k} ')
