@@ -138,13 +138,15 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
 // partial sums carries a relative variance error of ~2e-7 (1 + mean^2 / var): harmless on feature maps with mean ~ std, but 1 % of rstd
 // on the B nearly equal numbers of DeepLabV3+'s pooled ASPP branch, and visible (1e-5 of rstd, 1e-2 of small gradients) behind the +-8
 // BatchNorm biases of the kink-free parity nets on 2x2 .. 8x8 maps.  Small tensors cost nothing to read twice (they sit in L2); the
-// 704^2 workloads never take this path (their smallest BatchNorm sees 16 x 22 x 22 = 7744 values per channel).
-// Block = 32 channels x 8 row lanes; same outputs as bn_finalize_train_kernel.
+// 704^2 workloads at >= 4 frames per GPU never take this path (16 x 22 x 22 = 7744 values per channel in their smallest BatchNorm).
+// Block = 32 channels x 32 row lanes, four loads in flight per thread; same outputs as bn_finalize_train_kernel.
+// (BN_SMALL_COUNT = 1024: at 4096 with 8 row lanes the walk was ~100 us per BatchNorm and the 2 x 44 x 44 = 3872-value layer3 BatchNorms
+// of a 2-frame U-Net++/resnet101 step took it 69 times: 17.5 -> 30.9 ms per step, measured.)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_finalize_small_kernel(const void* y, int count, int C, const float* gamma, const float* beta,
-                                                                float* running_mean, float* running_var, float momentum, float eps,
-                                                                float* scale, float* shift, float* mean_out, float* rstd_out) {
-  __shared__ double red[8][33];
+__global__ __launch_bounds__(1024) void bn_finalize_small_kernel(const void* y, int count, int C, const float* gamma, const float* beta,
+                                                                 float* running_mean, float* running_var, float momentum, float eps,
+                                                                 float* scale, float* shift, float* mean_out, float* rstd_out) {
+  __shared__ double red[32][33];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const bool live = c < C;
@@ -152,19 +154,30 @@ __global__ __launch_bounds__(256) void bn_finalize_small_kernel(const void* y, i
     if (sizeof(T) == 4) return (double)((const float*)y)[(size_t)i * C + c];
     return (double)__uint_as_float((unsigned)((const unsigned short*)y)[(size_t)i * C + c] << 16);
   };
-  auto fold = [&](double x) -> double {   // sum over the 8 row lanes, in a fixed order, to every lane
+  auto fold = [&](double x) -> double {   // sum over the 32 row lanes, in a fixed order, to every lane
     __syncthreads();
     red[rl][cl] = x;
     __syncthreads();
     double t = 0.0;
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < 32; ++k) t += red[k][cl];
     return t;
   };
   double s = 0.0;
-  if (live) for (int i = rl; i < count; i += 8) s += val(i);
+  if (live) {
+    int i = rl;
+    for (; i + 96 < count; i += 128) { const double a0 = val(i), a1 = val(i + 32), a2 = val(i + 64), a3 = val(i + 96); s += (a0 + a1) + (a2 + a3); }
+    for (; i < count; i += 32) s += val(i);
+  }
   const double m = fold(s) / (double)count;
   double v = 0.0;
-  if (live) for (int i = rl; i < count; i += 8) { const double d = val(i) - m; v += d * d; }
+  if (live) {
+    int i = rl;
+    for (; i + 96 < count; i += 128) {
+      const double d0 = val(i) - m, d1 = val(i + 32) - m, d2 = val(i + 64) - m, d3 = val(i + 96) - m;
+      v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (; i < count; i += 32) { const double d = val(i) - m; v += d * d; }
+  }
   v = fold(v);
   if (!live || rl != 0) return;
   const double var = v / (double)count;
@@ -183,8 +196,8 @@ hipError_t launch_bn_finalize_small(int dtype, const void* y, int count, int C, 
                                     hipStream_t st) {
   OCTSEG_NO_F16(dtype);
   const dim3 grid((C + 31) / 32);
-  if (dtype == DT_F32) hipLaunchKernelGGL(bn_finalize_small_kernel<float>, grid, dim3(256), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
-  else hipLaunchKernelGGL(bn_finalize_small_kernel<bf16_t>, grid, dim3(256), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_finalize_small_kernel<float>, grid, dim3(1024), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
+  else hipLaunchKernelGGL(bn_finalize_small_kernel<bf16_t>, grid, dim3(1024), 0, st, y, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, rstd);
   return hipGetLastError();
 }
 

@@ -70,7 +70,7 @@ hipError_t launch_bn_finalize_train(const float* slab, int rows, int C, double c
 constexpr int SLAB_PART_CAP = 16384;
 // eval: scale/shift from the running statistics.
 // statistics of a tensor with <= BN_SMALL_COUNT values per channel, two-pass in double from the conv output itself (no slab)
-constexpr int BN_SMALL_COUNT = 4096;
+constexpr int BN_SMALL_COUNT = 1024;
 hipError_t launch_bn_finalize_small(int dtype, const void* y, int count, int C, const float* gamma, const float* beta, float* running_mean,
                                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
                                     hipStream_t st);
