@@ -22,6 +22,7 @@
 #include "conv_common.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ int p3_tx(int rr) {
 // instructions (profiles/r2_conv3x3p_probe.txt, profiles/r2_power_probe.txt).
 template <typename T, bool ILV>
 __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs a, const int n_nt, const int tiles_x, const int tiles_y,
-                                                                   const int nitems) {
+                                                                   const int nitems, const int gsz) {
   constexpr int NT = P3_NT, WN = P3_WN, WM = P3_WM, RB = P3_RB, BN = P3_BN, PITCH = P3_PITCH, SLAB = P3_SLAB;
   constexpr int KC = RB / 2, KSTEPS = RB / 32, VPR = RB / 16, NPASS = P3_NPASS, RW = P3_RW, OPITCH = P3_OPITCH;
   typedef WindowStager<T, RB, P3_NTHREADS> Stager;
@@ -65,16 +66,34 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   const int G = gridDim.x;
   const int wid = blockIdx.x;
   const int l = (G & 7) == 0 ? (wid & 7) * (G >> 3) + (wid >> 3) : wid;   // XCD x owns a contiguous range of the item order
-  const int nloc = (nitems - l + G - 1) / G;
+  // Item order.  gsz == 0 (legacy): N tile fastest, M tile slowest, dealt to the workgroups round by round (item l + j G) -- every XCD
+  // walks ALL N tiles all the time, and once their weights (9 K Cout 2 bytes) outgrow its 4 MB L2 every slab comes from beyond it
+  // (768 <- 256 @176^2: 1.6 GB fetched per launch for 0.25 GB of operands, profiles/r2_traffic.json).  gsz > 0: the N tiles are cut
+  // into groups of gsz whose weights fit an L2 next to the windows, the order is [group][M tile][N tile of the group], and XCD x owns
+  // the x-th EIGHTH of that list outright (its 32 CUs walk it side by side): an XCD meets one or two groups in a whole launch.  The
+  // price: the window of an M tile is fetched once per group instead of once.
+  const bool grouped = gsz > 0 && (G & 7) == 0;
+  const int cpx = G >> 3, seg = (nitems + 7) >> 3;
+  const int seg0 = (wid & 7) * seg, seg1 = min(nitems, seg0 + seg), cu = wid >> 3;
+  const int nloc = grouped ? max(0, (seg1 - seg0 - cu + cpx - 1) / cpx) : (nitems - l + G - 1) / G;
+  auto item_of = [&](int j) -> int { return grouped ? seg0 + cu + j * cpx : l + j * G; };
+  const int n_mt = nitems / n_nt, items_full = n_mt * (gsz > 0 ? gsz : 1), ngroups = gsz > 0 ? (n_nt + gsz - 1) / gsz : 1;
+  auto split = [&](int it, int& m, int& nt) {
+    if (!grouped) { nt = it % n_nt; m = it / n_nt; return; }
+    const int g = min(it / items_full, ngroups - 1);
+    const int itg = it - g * items_full, sz = min(gsz, n_nt - g * gsz);
+    m = itg / sz;
+    nt = g * gsz + itg - m * sz;
+  };
+  auto nt_of = [&](int it) -> int { int m, nt; split(it, m, nt); return nt; };
   const int nchunks = (a.Cin + KC - 1) / KC;
   const bool usrc = a.src_uniform != 0;
 
-  // item -> tile: N tile fastest (the N tiles of one M tile are neighbours in the item order: its window comes from HBM once)
   struct Tile { int n, y0, x0, nt, w_mt; };
   auto tile_of = [&](int it) -> Tile {
     Tile t;
-    t.nt = it % n_nt;
-    int m = it / n_nt;
+    int m;
+    split(it, m, t.nt);
     t.w_mt = m;
     t.n = m / (tiles_x * tiles_y);
     m -= t.n * tiles_x * tiles_y;
@@ -140,7 +159,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   // ---- weight slab cursor: two steps ahead of the consumer
   const char* Wp = (const char*)a.W;
   const long long slab_stride = (long long)n_nt * SLAB;   // between consecutive (tap, chunk) slabs of one N tile
-  int s_it = l, s_chunk = 0, s_tap = 0, s_nt = l % n_nt;
+  int s_j = 0, s_chunk = 0, s_tap = 0, s_nt = nt_of(item_of(0));
   uint4 B0, B1;                                           // slab registers (ILV: the set of the even steps ...
   uint4 C0 = make_uint4(0, 0, 0, 0), C1 = C0;             // ... and of the odd ones: a slab stays in registers for two taps)
   auto load_slab_into = [&](uint4& b0, uint4& b1) __attribute__((always_inline)) {
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       s_tap = 0;
       if (++s_chunk == nchunks) {
         s_chunk = 0;
-        if (s_it + G < nitems) { s_it += G; s_nt = s_it % n_nt; }   // past the last item: stay (harmless re-fetch)
+        if (s_j + 1 < nloc) { ++s_j; s_nt = nt_of(item_of(s_j)); }   // past the last item: stay (harmless re-fetch)
       }
     }
   };
@@ -166,10 +185,14 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     if constexpr (TI == 8) {
       const bool wrap = s_chunk + 1 == nchunks;
       s_chunk = wrap ? 0 : s_chunk + 1;
-      const bool more = wrap && s_it + G < nitems;
-      s_it = more ? s_it + G : s_it;
-      const int nn = s_nt + g_mod;
-      s_nt = more ? (nn >= n_nt ? nn - n_nt : nn) : s_nt;
+      const bool more = wrap && s_j + 1 < nloc;
+      s_j += more ? 1 : 0;
+      if (grouped) {                       // (kernel-uniform branch)
+        s_nt = nt_of(item_of(s_j));
+      } else {
+        const int nn = s_nt + g_mod;
+        s_nt = more ? (nn >= n_nt ? nn - n_nt : nn) : s_nt;
+      }
     }
   };
   auto store_slab_from = [&](int slot, const uint4& b0, const uint4& b1) __attribute__((always_inline)) {
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
   bool sl_ok = false, sl2_ok = false;
 
   // ---- prologue: window of (first tile, chunk 0), slab of step 0 in slot 0, slab of step 1 in registers
-  Tile cur = tile_of(l);
+  Tile cur = tile_of(item_of(0));
   {
     setup_next(cur, 0);
     load_slab();
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     frag_load(1, ldsA, t0, ldsB, 1);
   }
 
-  int it = l, chunk = 0, cb = 0;   // consumer: item, chunk, window buffer of the chunk
+  int jt = 0, chunk = 0, cb = 0;   // consumer: local item number, chunk, window buffer of the chunk
   Tile nt_tile = cur;              // tile of the chunk being staged
 
   // ---- epilogue of the finished tile `cur` through window buffer `buf` (every wave is past its last read of it)
@@ -397,7 +420,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
     if constexpr (TT == 0) {   // which chunk is staged during this one: the next chunk of the tile, or the first of the next tile
       if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
-      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+      else { nt_tile = tile_of(item_of(jt + 1 < nloc ? jt + 1 : jt)); setup_next(nt_tile, 0); }
     }
     // what the previous tap loaded goes to LDS (the slab of the next step, window pass TT - 1 of the chunk being staged), then this
     // tap's loads are issued (the slab of step g + 2, window pass TT): a whole tap of MFMAs to land behind
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
     if constexpr (TT == 0) {
       if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
-      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+      else { nt_tile = tile_of(item_of(jt + 1 < nloc ? jt + 1 : jt)); setup_next(nt_tile, 0); }
     }
     const int toff = __builtin_amdgcn_readlane(v_toff, TT);
     const char* bsl = ldsB + (TT % 3) * SLAB;
@@ -505,7 +528,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     char* anext = ldsA + (cb ^ 1) * P3_ABYTES;
     if constexpr (TT == 0) {
       if (chunk + 1 < nchunks) setup_next(cur, chunk + 1);
-      else { nt_tile = tile_of(it + G < nitems ? it + G : it); setup_next(nt_tile, 0); }
+      else { nt_tile = tile_of(item_of(jt + 1 < nloc ? jt + 1 : jt)); setup_next(nt_tile, 0); }
     }
     const int toff = __builtin_amdgcn_readlane(v_toff, TT);
     constexpr int R0 = TT % 3;
@@ -573,7 +596,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
     if (chunk + 1 < nchunks) { ++chunk; }
     else {
       epilogue(ldsA + cb * P3_ABYTES);
-      chunk = 0; it += G; cur = nt_tile;
+      chunk = 0; ++jt; cur = nt_tile;
     }
     cb ^= 1;
   };
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
 }
 
 namespace {
-struct P3Geom { int tiles_x, tiles_y, n_mt, n_nt, nitems, G; size_t lds; };
+struct P3Geom { int tiles_x, tiles_y, n_mt, n_nt, nitems, G, gsz; size_t lds; };
 static P3Geom p3_geom(const ConvArgs& a) {
   P3Geom g;
   g.tiles_x = a.OW / TW; g.tiles_y = a.OH / P3_TH;
@@ -594,6 +617,19 @@ static P3Geom p3_geom(const ConvArgs& a) {
   g.nitems = g.n_mt * g.n_nt;
   g.G = g.nitems < 256 ? g.nitems : 256;   // one workgroup per CU (gfx950 / MI355X only build)
   g.lds = (size_t)2 * P3_ABYTES + 2 * P3_SLAB;   // (+1 slab with ILV, added at launch)
+  // N-tile groups (kernel header): only where the weights of all N tiles together outgrow an L2's share (2 MB); a group holds what fits
+  // the budget.  OPT-IN (OCTSEG_P3_GROUP_KB=1536): measured on U-Net++/resnet101 16 x 704^2 in one run, the grouped order cuts the
+  // kernel's TCC fetch from 1333 to 1146 MB per launch (-14 %, profiles/r3_p3_item_order.txt) and leaves its time where it was
+  // (decoder data gradients 15.32 -> 15.43 ms per step, forward 13.70 -> 13.69: noise) -- the slabs it saves came from the 256 MB
+  // Infinity Cache, not from HBM, and the loop's time follows the energy of its MFMAs.
+  static const int group_kb = getenv("OCTSEG_P3_GROUP_KB") ? atoi(getenv("OCTSEG_P3_GROUP_KB")) : 0;   // A/B switch
+  static const int all_kb = getenv("OCTSEG_P3_ALL_KB") ? atoi(getenv("OCTSEG_P3_ALL_KB")) : 2048;
+  const long long per_nt = 9LL * a.Cin * P3_BN * 2;
+  g.gsz = 0;
+  if (group_kb > 0 && g.G == 256 && per_nt * g.n_nt > (long long)all_kb * 1024) {
+    g.gsz = (int)std::max<long long>(1, (long long)group_kb * 1024 / per_nt);
+    if (g.gsz >= g.n_nt) g.gsz = 0;
+  }
   return g;
 }
 }  // namespace
@@ -628,7 +664,8 @@ static hipError_t p3_launch_k(const ConvArgs& a, const P3Geom& g, hipStream_t st
     if (e != hipSuccess) return e;
     set = true;
   }
-  hipLaunchKernelGGL((conv3x3p_kernel<T, ILV>), dim3(g.G), dim3(P3_NTHREADS), g.lds + (ILV ? P3_SLAB : 0), st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems);
+  hipLaunchKernelGGL((conv3x3p_kernel<T, ILV>), dim3(g.G), dim3(P3_NTHREADS), g.lds + (ILV ? P3_SLAB : 0), st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems,
+                     g.gsz);
   return hipGetLastError();
 }
 template <typename T>
