@@ -333,7 +333,8 @@ def test_reference_attribute_paths(cuda):
         m.model.encoder.layer5
 
 
-@pytest.mark.parametrize('arch,enc,dtype', [('unetplusplus', 'resnet18', torch.float32), ('linknet', 'resnet50', torch.bfloat16), ('fpn', 'resnet18', torch.float32)])
+@pytest.mark.parametrize('arch,enc,dtype', [('unetplusplus', 'resnet18', torch.float32), ('linknet', 'resnet50', torch.bfloat16), ('fpn', 'resnet18', torch.float32),
+                                            ('deeplabv3plus', 'resnet18', torch.float32)])
 def test_captured_training_step_equals_eager_bit_for_bit(cuda, arch, enc, dtype):
     """octseg_net_train_step under octseg_plan_set_train_graph: warm-up call, capture, replay -- the replayed hipGraph (weight packing,
     forward lanes, the weight-gradient side stream and every event edge inside) must leave loss, logits, confusion counts, BatchNorm
@@ -345,6 +346,8 @@ def test_captured_training_step_equals_eager_bit_for_bit(cuda, arch, enc, dtype)
     img, mask = (t.to(cuda) for t in make_batch(2, classes, 64, seed=31))
     img2, mask2 = (t.to(cuda) for t in make_batch(2, classes, 64, seed=32))
     keep = (torch.rand(2, 128, generator=torch.Generator().manual_seed(4)) < 0.8).float()
+    if arch == 'deeplabv3plus':                      # element-wise pattern of ASPP.project's dropout, NHWC
+        keep = (torch.rand(2, 4, 4, 256, generator=torch.Generator().manual_seed(4)) < 0.5).float()
     L.check(L.lib().octseg_set_deterministic(1))
     try:
         def run(graph):
@@ -368,3 +371,21 @@ def test_captured_training_step_equals_eager_bit_for_bit(cuda, arch, enc, dtype)
         for name, x, y in zip(('loss', 'logits', 'stats', 'grads', 'bn_buffers'), a, b):
             assert torch.equal(x, y), f'step {k}: {name} differs between the captured and the eager step'
     assert not torch.equal(eager[1][3], eager[2][3]) and not torch.equal(eager[1][3], eager[3][3])
+
+
+@pytest.mark.parametrize('arch', ['FPN', 'DeepLabV3Plus'])
+def test_sweep_architectures_through_the_model_class(cuda, tmp_path, arch):
+    """The reference's sweep passes `architecture` straight to smp.create_model (configs/tune.yaml:9-18, model.py:38-44): the mirror class
+    trains, validates, checkpoints and predicts with the two sweep architectures of round 3 exactly as with the BASELINE trio."""
+    from oct_segmentation_amd.config import load_config
+    from oct_segmentation_amd.predict import load_model
+    from oct_segmentation_amd.train import fit
+    cfg = load_config('train', [f'architecture={arch}', 'encoder=resnet18', 'epochs=2', 'input_size=64', 'batch_size=2', 'lr=0.001',
+                                'compute_dtype=bf16', 'use_augmentation=false'])
+    cfg['classes'] = ['Lipid core', 'Fibrous cap']
+    batches = [tuple(t.to(cuda) for t in make_batch(2, 2, 64, seed=s)) for s in (1, 2, 3)]
+    model, hist = fit(cfg, batches, val_batches=batches[:1], device=cuda, model_dir=str(tmp_path))
+    assert len(hist) == 2 and all(np.isfinite(float(h['train']['loss'])) for h in hist)
+    m2, _ = load_model(str(tmp_path), 'cuda', torch.float16)          # serving dtype
+    out = m2.predict(np.zeros((1, 64, 64, 3), np.float32), 'cuda')
+    assert out.shape == (1, 64, 64, 2) and set(np.unique(out)) <= {0.0, 1.0}
