@@ -50,7 +50,10 @@ __device__ __forceinline__ int p3_tx(int rr) {
 // (branch-free staging, slab cursor resolved at compile time).  Both are bit-identical; on one box they run within 2 % of each other,
 // because on real operands the loop sits on the 1400 W package limit and its time follows the energy of a tile, not the order of its
 // instructions (profiles/r2_conv3x3p_probe.txt, profiles/r2_power_probe.txt).
-template <typename T, bool ILV>
+// NOAFF (ILV only): no source carries a lazy BatchNorm or ReLU (the data gradients: dy is a plain tensor) -- the staged window words go to
+// LDS as loaded instead of through the identity affine (unpack, v_pk_fma, v_cvt_pk, v_pk_max: 20 vector instructions per tap and thread).
+// Bit-identical by construction (x * 1 + 0 rounds to x).
+template <typename T, bool ILV, bool NOAFF = false>
 __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs a, const int n_nt, const int tiles_x, const int tiles_y,
                                                                    const int nitems, const int gsz) {
   constexpr int NT = P3_NT, WN = P3_WN, WM = P3_WM, RB = P3_RB, BN = P3_BN, PITCH = P3_PITCH, SLAB = P3_SLAB;
@@ -493,7 +496,8 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       if constexpr (WST && (I == 8 || I == 9 || I == 10 || I == 12)) {
         constexpr int k = I == 12 ? 3 : I - 8;
         const unsigned w = k == 0 ? wsl.x : k == 1 ? wsl.y : k == 2 ? wsl.z : wsl.w;
-        wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
+        if constexpr (NOAFF) wv[k] = w;
+        else wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
       }
       if constexpr (WST && I == 13) {
         const uint4 v = wok ? make_uint4(wv[0], wv[1], wv[2], wv[3]) : make_uint4(0, 0, 0, 0);
@@ -563,7 +567,8 @@ __global__ __launch_bounds__(P3_NTHREADS, 1) void conv3x3p_kernel(const ConvArgs
       if constexpr (WST && I >= 2 && I <= 5) {
         constexpr int k = I - 2;
         const unsigned w = k == 0 ? wsl.x : k == 1 ? wsl.y : k == 2 ? wsl.z : wsl.w;
-        wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
+        if constexpr (NOAFF) wv[k] = w;
+        else wv[k] = Tr<T>::affine_floor1(w, nxt.sc[2 * k], nxt.sc[2 * k + 1], nxt.sh[2 * k], nxt.sh[2 * k + 1], nxt.fl16);
       }
       if constexpr (WST && I == 6) {
         const uint4 v = wok ? make_uint4(wv[0], wv[1], wv[2], wv[3]) : make_uint4(0, 0, 0, 0);
@@ -656,23 +661,29 @@ bool conv3x3p_eligible(const ConvArgs& a, int dtype) {
 
 int conv3x3p_rows(const ConvArgs& a) { return p3_geom(a).n_mt; }
 
-template <typename T, bool ILV>
+template <typename T, bool ILV, bool NOAFF = false>
 static hipError_t p3_launch_k(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
   static bool set = false;
   if (!set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<T, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<T, ILV, NOAFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     set = true;
   }
-  hipLaunchKernelGGL((conv3x3p_kernel<T, ILV>), dim3(g.G), dim3(P3_NTHREADS), g.lds + (ILV ? P3_SLAB : 0), st, a, g.n_nt, g.tiles_x, g.tiles_y, g.nitems,
-                     g.gsz);
+  hipLaunchKernelGGL((conv3x3p_kernel<T, ILV, NOAFF>), dim3(g.G), dim3(P3_NTHREADS), g.lds + (ILV ? P3_SLAB : 0), st, a, g.n_nt, g.tiles_x, g.tiles_y,
+                     g.nitems, g.gsz);
   return hipGetLastError();
 }
 template <typename T>
 static hipError_t p3_launch(const ConvArgs& a, const P3Geom& g, hipStream_t st) {
   static const bool plain = getenv("OCTSEG_P3_PLAIN") != nullptr;   // A/B switch: the head-of-tap variant
+  static const bool keep_aff = getenv("OCTSEG_P3_AFF") != nullptr;  // A/B switch: identity affine also where no source needs one
   if constexpr (std::is_same<T, f16_t>::value) return p3_launch_k<T, false>(a, g, st);   // (the interleaved variant's f16 instantiation spills)
-  else return plain ? p3_launch_k<T, false>(a, g, st) : p3_launch_k<T, true>(a, g, st);
+  else {
+    if (plain) return p3_launch_k<T, false>(a, g, st);
+    bool noaff = !keep_aff;
+    for (int i = 0; i < a.nsrc; ++i) noaff = noaff && a.src[i].scale == nullptr && a.src[i].shift == nullptr && a.src[i].relu == 0;
+    return noaff ? p3_launch_k<T, true, true>(a, g, st) : p3_launch_k<T, true, false>(a, g, st);
+  }
 }
 
 hipError_t launch_conv3x3p(int dtype, const ConvArgs& a0, hipStream_t st) {
