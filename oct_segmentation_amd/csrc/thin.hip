@@ -115,6 +115,16 @@ __device__ __forceinline__ void thin_stage(const ThinArgs& a, char* lds, int n, 
 // LDS as T; (2) after a barrier every thread assembles its im2col vectors from that window with LDS reads (a 160-entry offset table, one
 // 16-byte table read per vector).  (Gathering the 147 taps of every pixel from global memory took 8 scalar loads per vector and five
 // dependent round trips per tile: 1.1 ms for the stem forward, measured.)
+// Stem forward: k-steps of a tile unrolled by 2, two waves per SIMD.  Fully unrolled (six k-steps x four weight blocks of LDS reads hoisted
+// in front of the MFMAs) the kernel sat at 256 registers with 63 spilled: 0.47 ms; unrolled by 2 it needs 216 and spills nothing: 0.32 ms
+// (U-Net/resnet50 704^2 step 644 -> 650 frames/s).  Three waves per SIMD with 768 workgroups spill 49 registers: 0.44 ms.  Fewer, larger
+// tiles (TH = 8) or 256 workgroups are slower (0.54 / 0.62 ms): the kernel lives on workgroups in flight, not on work per workgroup.
+#ifndef STEM_WPS
+#define STEM_WPS 2
+#endif
+#ifndef STEM_UNROLL
+#define STEM_UNROLL 2
+#endif
 constexpr int STEM_WC = 72;                                     // window row pitch in elements (69 used)
 template <int TH> struct StemWin {
   static constexpr int ROWS = 2 * TH + 5, ELEMS = 3 * ROWS * STEM_WC;
@@ -195,7 +205,7 @@ __device__ __forceinline__ void stem_build(char* lds, const char* aux, int tid) 
 }  // namespace
 
 template <typename T, int KIND, int CIN, int NB, int TH>
-__global__ __launch_bounds__(THIN_NTHR, NB == 1 ? 3 : 2) void thin_conv_kernel(const ThinArgs a) {
+__global__ __launch_bounds__(THIN_NTHR, NB == 1 ? 3 : (KIND == KSTEM ? STEM_WPS : 2)) void thin_conv_kernel(const ThinArgs a) {
   typedef ThinK<KIND, CIN> K;
   constexpr int PIXB = K::PIXB, RW = K::RW, HALO = K::HALO;
   constexpr bool STEM = K::STEM;
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(THIN_NTHR, NB == 1 ? 3 : 2) void thin_conv_kernel(c
           f32x4_t acc[NB];
 #pragma unroll
           for (int b = 0; b < NB; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll(STEM ? STEM_UNROLL : STEPS)
           for (int s = 0; s < STEPS; ++s) {
             uint4 bf;
             if constexpr (STEM) {   // 4-byte aligned (12 bytes per output pixel): four dwords
@@ -720,8 +730,9 @@ hipError_t launch_thin_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
 // ---- the ResNet stem (conv 7x7 stride 2 pad 3, 3 -> 64) on the NCHW f32 frame
 bool thin_stem_eligible(int dtype) { return thin_ext_on() && dtype != DT_F32; }
 static ThinGeom stem_geom(int N, int H, int W) {   // ~225 registers per lane: two workgroups per CU, one resident round
+  static const int gcap = getenv("OCTSEG_STEM_G") ? atoi(getenv("OCTSEG_STEM_G")) : 512;   // experiments
   ThinGeom g = thin_geom(N, H / 2, W / 2, 4);
-  if (g.G > 512) g.G = 512;
+  if (g.G > gcap) g.G = gcap;
   return g;
 }
 int thin_stem_rows(int N, int H, int W) { return stem_geom(N, H, W).G; }
