@@ -31,7 +31,7 @@ def test_no_instruction_touches_an_asm_load_destination_in_flight():
 @pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
 def test_conv3x3p_barrier_leaves_only_fragment_reads_in_flight(tmp_path):
     """conv3x3p's interleaved tap ends with `s_waitcnt lgkmcnt(N)` + `s_barrier` (hipcc does not model it): the N youngest LGKM operations
-    must be fragment reads in each of its 18 unrolled taps (tools/audit_p3_barrier.py); and the checker itself must
+    must be fragment reads in each of the 18 unrolled taps of both interleaved instantiations (with / without the staging affine; tools/audit_p3_barrier.py); and the checker itself must
     reject an LDS store moved into that window."""
     csrc = os.path.join(ROOT, 'oct_segmentation_amd', 'csrc')
     isa = os.path.join(csrc, 'build', 'conv3x3p.s')
@@ -43,7 +43,7 @@ def test_conv3x3p_barrier_leaves_only_fragment_reads_in_flight(tmp_path):
     tool = os.path.join(ROOT, 'tools', 'audit_p3_barrier.py')
     r = subprocess.run([sys.executable, tool, isa], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.startswith('18 interleaved-tap barriers audited, 0 violations'), r.stdout
+    assert r.stdout.startswith('36 interleaved-tap barriers audited, 0 violations'), r.stdout
     # negative control: swap the youngest fragment read of the first audited barrier for an LDS store
     lines = open(isa).read().split('\n')
     def next_ins(i):
