@@ -32,6 +32,9 @@ CASES = {
     'c1_unet_resnet18_256': ('unet', 'resnet18', 1, 2, 256, 116),
     # the encoder of BASELINE config c2 (U-Net++ / resnet101: 23 bottlenecks in layer3), tiny frame
     'unetplusplus_resnet101': ('unetplusplus', 'resnet101', 1, 2, 64, 120),
+    # the sweep architectures of round 3; their dropout keep patterns are derived from the seed (case_keep)
+    'fpn_resnet18_64x96': ('fpn', 'resnet18', 2, 2, (64, 96), 140),
+    'deeplabv3plus_resnet18_64x96': ('deeplabv3plus', 'resnet18', 2, 4, (64, 96), 141),
 }
 # Lightning-DDP semantics (reference train.py:122-133 with devices > 1): the global batch is split
 # into `world` contiguous shards, every rank runs forward + Dice + backward on ITS shard with local BatchNorm statistics
@@ -45,14 +48,32 @@ DDP_CASES = {
 FULL_LOGITS_MAX = 64 * 1024
 
 
-def case_batch(B, classes, S, seed):
-    """Synthetic batch of a case; a (H, W) size is cut out of the square frame of side max(H, W)."""
+def case_batch(B, classes, S, seed, arch=None):
+    """Synthetic batch of a case; a (H, W) size is cut out of the square frame of side max(H, W).  DeepLabV3+ frames get a brightness of
+    their own each: its pooled ASPP branch normalises B values per channel, and BatchNorm of B nearly equal numbers amplifies rounding
+    without bound (tests/test_gpu_deeplab.py)."""
     from synth import make_batch
     if isinstance(S, tuple):
         H, W = S
         img, mask = make_batch(B, classes, max(H, W), seed=seed, empty_last=(classes > 1))
-        return img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
-    return make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+        img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
+    else:
+        img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
+    if arch == 'deeplabv3plus':
+        img = (img * (0.35 + 0.65 * torch.arange(B).view(B, 1, 1, 1) / max(1, B - 1))).round().contiguous()
+    return img, mask
+
+
+def case_keep(arch, B, S, seed):
+    """Dropout keep pattern of a case in torch's layout: FPN Dropout2d [B, 128] (p = 0.2), DeepLabV3+ element-wise [B, 256, H/16, W/16]
+    (p = 0.5); None for the architectures without dropout."""
+    H, W = S if isinstance(S, tuple) else (S, S)
+    g = torch.Generator().manual_seed(seed + 2)
+    if arch == 'fpn':
+        return (torch.rand(B, 128, generator=g) < 0.8).float()
+    if arch == 'deeplabv3plus':
+        return (torch.rand(B, 256, H // 16, W // 16, generator=g) < 0.5).float()
+    return None
 
 
 def summarize_logits(z):
@@ -80,13 +101,23 @@ def build(arch, enc, classes, seed, kinkfree=True):
             for mod in m.modules():
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.bias.copy_(8.0 * ((torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+            if arch in ('fpn', 'deeplabv3plus'):
+                # their heads sit straight behind normalisation layers with +-8 biases (summed four times in FPN): keep |logits| of order 1,
+                # a saturated sigmoid has no gradient to compare
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.GroupNorm):
+                        mod.bias.copy_(8.0 * ((torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1))
+                m.segmentation_head[0].weight.mul_(0.03)
     return m.train()
 
 
 def run_case(arch, enc, classes, B, S, seed):
     from oracle import DiceLoss, get_stats
     m = build(arch, enc, classes, seed)
-    img, mask = case_batch(B, classes, S, seed)
+    img, mask = case_batch(B, classes, S, seed, arch)
+    keep = case_keep(arch, B, S, seed)
+    if keep is not None:
+        m.decoder.dropout.mask = keep
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     logits = m((img - mean) / std)

@@ -13,9 +13,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 
 @pytest.mark.parametrize('name', ['unet_resnet18', 'unetplusplus_resnet18', 'linknet_resnet18', 'unet_resnet50', 'unetplusplus_resnet50',
-                                  'linknet_resnet50', 'unet_resnet18_96x64', 'c1_unet_resnet18_256', 'unetplusplus_resnet101'])
+                                  'linknet_resnet50', 'unet_resnet18_96x64', 'c1_unet_resnet18_256', 'unetplusplus_resnet101',
+                                  'fpn_resnet18_64x96', 'deeplabv3plus_resnet18_64x96'])
 def test_engine_reproduces_golden_vectors(cuda, name):
-    from golden.make_golden import CASES, build, case_batch, summarize_logits
+    from golden.make_golden import CASES, build, case_batch, case_keep, summarize_logits
     from oct_segmentation_amd.engine import SegNet
     arch, enc, classes, B, S, seed = CASES[name]
     g = np.load(os.path.join(GOLDEN, f'{name}.npz'))
@@ -23,7 +24,8 @@ def test_engine_reproduces_golden_vectors(cuda, name):
     net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=torch.float32)
     net.load_state_dict(ref.state_dict())
     net.train()
-    img, mask = case_batch(B, classes, S, seed)
+    img, mask = case_batch(B, classes, S, seed, arch)
+    net.dropout_keep = case_keep(arch, B, S, seed)     # (None for the architectures without dropout)
     loss, logits, stats = net.train_step_raw(img.to(cuda), mask.to(cuda), normalize=True,
                                              mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
     torch.cuda.synchronize()
