@@ -135,6 +135,23 @@ def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     assert judge_gradients(ref, grads, img, mask) <= 1
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 704, 704), (3, 352, 416)])
+def test_deeplab_dilation_rates_in_range_fp32(cuda, B, H, W):
+    """The small frames above leave the ASPP's rates (12, 24, 36) outside their 4x4 .. 8x8 maps: only the centre taps of the dilated
+    depthwise convs ever touch data there.  At the BASELINE frame size the stride-16 map is 44 x 44 (and 22 x 26 for the second case) and
+    every tap of every rate lands inside: the same fp32 bounds, against the same oracle, kink-free."""
+    from test_gpu_net import _grad_report
+    ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, 'resnet18', 1, B, H, W, seed=7, kinkfree=True)
+    grads = net.named_grads()
+    cos, worst, name = _grad_report(grads, ref)
+    err = (logits - z).abs().max().item()
+    print(f'deeplabv3plus/resnet18 B{B} {H}x{W} kink-free: logits {err:.2e} / {z.abs().max().item():.2f}, loss {abs(loss.item() - loss_ref.item()):.1e}, grad cosine {cos:.9f}, worst {worst:.2e} ({name})')
+    assert err <= 1e-4 * max(1.0, z.abs().max().item())
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert cos >= 0.999999
+    judge_gradients(ref, grads, img, mask)
+
+
 def test_deeplab_eval_forward_and_batch_of_one(cuda):
     """Eval: dropout is the identity, BatchNorm uses running statistics: logits equal the oracle's eval forward -- also for a batch of one.
     Training a batch of one raises torch's own error (the pooled branch's BatchNorm has one value per channel).  Training without an
