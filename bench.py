@@ -43,6 +43,7 @@ WORKLOADS = {
     'unet_r18_256': ('unet', 'resnet18', 1, 256),
     'fpn_r50_704': ('fpn', 'resnet50', 1, 704),       # sweep architectures outside BASELINE's three
     'deeplabv3plus_r50_704': ('deeplabv3plus', 'resnet50', 1, 704),
+    'pspnet_r50_704': ('pspnet', 'resnet50', 1, 704),
 }
 
 

@@ -1,4 +1,4 @@
-// deeplab.hip -- the HBM-bound kernels that the DeepLabV3+ decoder adds to the hot path (gfx950): depthwise (dilated) 3x3 convolution
+// deeplab.hip -- the HBM-bound kernels that the DeepLabV3+ and PSPNet decoders add to the hot path (gfx950): depthwise (dilated) 3x3 convolution
 // forward / data gradient / weight gradient, the space <-> batch permutation that turns ResNet layer4 at dilation 2 into ordinary 3x3
 // convolutions, image pooling (global mean) and its broadcast, element-wise dropout with an injected keep mask, and the plain bilinear
 // (align_corners=True) resample between NHWC tensors.
@@ -302,6 +302,216 @@ hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H
   const size_t nvec = (size_t)N * H * up * W * up * (C / vec);
   const float sy = H * up > 1 ? (float)(H - 1) / (float)(H * up - 1) : 0.f, sx = W * up > 1 ? (float)(W - 1) / (float)(W * up - 1) : 0.f;
   DL_DISPATCH(bilinear_up_kernel, dim3(grid_for(nvec, 256)), in, out, N, H, W, C / vec, up, sy, sx);
+  return hipGetLastError();
+}
+
+// ================================================================== PSPNet (smp decoders/pspnet, restated in oracle/nets.py PSPDecoder)
+// ------------------------------------------------------------------ nn.AdaptiveAvgPool2d((k, k)): bin i covers [floor(i H / k), ceil((i + 1) H / k))
+// (neighbouring bins overlap by a row / column when k does not divide H).  out [N][k][k][C]; grid (ceil(vpc / DW_CH), N k k), deterministic.
+static __device__ __forceinline__ void bin_range(int i, int k, int H, int& lo, int& hi) { lo = (i * H) / k; hi = ((i + 1) * H + k - 1) / k; }
+template <typename T>
+__global__ __launch_bounds__(256) void bin_mean_kernel(const void* in, void* out, int H, int W, int k, int vpc) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int v0 = blockIdx.x * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
+  const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
+  const int bin = blockIdx.y % (k * k);
+  const size_t n = blockIdx.y / (k * k);
+  int y0, y1, x0, x1;
+  bin_range(bin / k, k, H, y0, y1);
+  bin_range(bin % k, k, W, x0, x1);
+  const int bw = x1 - x0, cnt = (y1 - y0) * bw;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  if (r < rows)
+    for (int p = r; p < cnt; p += rows) {
+      const int y = y0 + p / bw, x = x0 + p % bw;
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(in, ((n * H + y) * W + x) * vpc + v0 + cv), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += f[i];
+    }
+  if (r < rows)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(r * nv + cv) * VEC + i] = s[i];
+  __syncthreads();
+  if (r == 0) {
+    for (int q = 1; q < rows; ++q)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += red[(q * nv + cv) * VEC + i];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] /= (float)cnt;
+    stv<T>(out, (size_t)blockIdx.y * vpc + v0 + cv, EV<T>::pack(s));
+  }
+}
+hipError_t launch_bin_mean(int dtype, const void* in, void* out, int N, int H, int W, int C, int k, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || k < 1) return hipErrorInvalidValue;
+  const int vpc = C / vec;
+  DL_DISPATCH(bin_mean_kernel, dim3((vpc + DW_CH - 1) / DW_CH, N * k * k), in, out, H, W, k, vpc);
+  return hipGetLastError();
+}
+// its gradient, gather form: gin[n][y][x] (+)= sum over the bins that contain (y, x) of gout[bin] / area(bin)
+template <typename T>
+__global__ __launch_bounds__(256) void bin_mean_bwd_kernel(const void* gout, void* gin, int N, int H, int W, int k, int vpc, int accum) {
+  constexpr int VEC = EV<T>::VEC;
+  const size_t nvec = (size_t)N * H * W * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const size_t n = p / H;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int bi = 0; bi < k; ++bi) {            // (k <= 6: every bin is tried; with k > H several bins hold the same pixel)
+      int y0, y1;
+      bin_range(bi, k, H, y0, y1);
+      if (y < y0 || y >= y1) continue;
+      for (int bj = 0; bj < k; ++bj) {
+        int x0, x1;
+        bin_range(bj, k, W, x0, x1);
+        if (x < x0 || x >= x1) continue;
+        float f[VEC];
+        EV<T>::unpack(ldv<T>(gout, ((n * k + bi) * k + bj) * vpc + cv), f);
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(f[i], inv, acc[i]);
+      }
+    }
+    put<T>(gin, v, acc, accum);
+  }
+}
+hipError_t launch_bin_mean_bwd(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int k, int accum, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || k < 1) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * H * W * (C / vec);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bin_mean_bwd_kernel<float>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, gout, gin, N, H, W, k, C / vec, accum);
+  else hipLaunchKernelGGL(bin_mean_bwd_kernel<bf16_t>, dim3(grid_for(nvec, 256)), dim3(256), 0, st, gout, gin, N, H, W, k, C / vec, accum);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ F.interpolate(size=(OH, OW), mode='bilinear', align_corners=True), any size pair
+struct Tap2 { int i0, i1; float w0, w1; };
+static __device__ __forceinline__ Tap2 tap_of(int o, int in, float scale) {   // torch: x = scale * o, i0 = (int)x, lambda1 = x - i0
+  const float x = scale * (float)o;
+  Tap2 t;
+  t.i0 = min((int)x, in - 1);
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.w1 = x - (float)t.i0;
+  t.w0 = 1.f - t.w1;
+  return t;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_resize_kernel(const void* in, void* out, int N, int IH, int IW, int OH, int OW, int vpc, float sy, float sx) {
+  constexpr int VEC = EV<T>::VEC;
+  const size_t nvec = (size_t)N * OH * OW * vpc;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(v % vpc);
+    size_t p = v / vpc;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const size_t n = p / OH;
+    const Tap2 ty = tap_of(oy, IH, sy), tx = tap_of(ox, IW, sx);
+    float a00[VEC], a01[VEC], a10[VEC], a11[VEC], o[VEC];
+    EV<T>::unpack(ldv<T>(in, ((n * IH + ty.i0) * IW + tx.i0) * vpc + cv), a00);
+    EV<T>::unpack(ldv<T>(in, ((n * IH + ty.i0) * IW + tx.i1) * vpc + cv), a01);
+    EV<T>::unpack(ldv<T>(in, ((n * IH + ty.i1) * IW + tx.i0) * vpc + cv), a10);
+    EV<T>::unpack(ldv<T>(in, ((n * IH + ty.i1) * IW + tx.i1) * vpc + cv), a11);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = ty.w0 * (tx.w0 * a00[i] + tx.w1 * a01[i]) + ty.w1 * (tx.w0 * a10[i] + tx.w1 * a11[i]);
+    stv<T>(out, v, EV<T>::pack(o));
+  }
+}
+static inline float resize_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+hipError_t launch_bilinear_resize(int dtype, const void* in, void* out, int N, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)N * OH * OW * (C / vec);
+  DL_DISPATCH(bilinear_resize_kernel, dim3(grid_for(nvec, 256)), in, out, N, IH, IW, OH, OW, C / vec, resize_scale(IH, OH), resize_scale(IW, OW));
+  return hipGetLastError();
+}
+// adjoint, gather form (the source is a handful of pixels: k x k bins): one block per (image, source pixel, 32-vector channel chunk) walks
+// the outputs that can touch that pixel -- its threads share them out, fold through LDS in a fixed order -- and adds the very weights the
+// forward used; one writer per element.  (One THREAD per source element took 12 ms of a 25 ms PSPNet step: 256 threads walking 88 x 88
+// outputs each for the 1x1 bin.)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_resize_adjoint_kernel(const void* gout, void* gin, int IH, int IW, int OH, int OW, int vpc,
+                                                                      float sy, float sx) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int v0 = blockIdx.x * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
+  const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
+  const int pix = blockIdx.y % (IH * IW);
+  const size_t n = blockIdx.y / (IH * IW);
+  const int iy = pix / IW, ix = pix - iy * IW;
+  int oy0 = 0, oy1 = OH - 1, ox0 = 0, ox1 = OW - 1;
+  if (sy > 0.f) { oy0 = max(0, (int)floorf((float)(iy - 1) / sy) - 1); oy1 = min(OH - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
+  if (sx > 0.f) { ox0 = max(0, (int)floorf((float)(ix - 1) / sx) - 1); ox1 = min(OW - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
+  const int bw = ox1 - ox0 + 1, cnt = (oy1 - oy0 + 1) * bw;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (r < rows)
+    for (int q = r; q < cnt; q += rows) {
+      const int oy = oy0 + q / bw, ox = ox0 + q % bw;
+      const Tap2 ty = tap_of(oy, IH, sy), tx = tap_of(ox, IW, sx);
+      const float w = ((ty.i0 == iy ? ty.w0 : 0.f) + (ty.i1 == iy ? ty.w1 : 0.f)) * ((tx.i0 == ix ? tx.w0 : 0.f) + (tx.i1 == ix ? tx.w1 : 0.f));
+      if (w == 0.f) continue;
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(gout, ((n * OH + oy) * OW + ox) * vpc + v0 + cv), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(f[i], w, acc[i]);
+    }
+  if (r < rows)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(r * nv + cv) * VEC + i] = acc[i];
+  __syncthreads();
+  if (r == 0) {
+    for (int q = 1; q < rows; ++q)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += red[(q * nv + cv) * VEC + i];
+    stv<T>(gin, (size_t)blockIdx.y * vpc + v0 + cv, EV<T>::pack(acc));
+  }
+}
+hipError_t launch_bilinear_resize_adjoint(int dtype, const void* gout, void* gin, int N, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || (long long)N * IH * IW > 65535) return hipErrorInvalidValue;
+  const int vpc = C / vec;
+  const float sy = resize_scale(IH, OH), sx = resize_scale(IW, OW);
+  const dim3 grid((vpc + DW_CH - 1) / DW_CH, N * IH * IW);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bilinear_resize_adjoint_kernel<float>, grid, dim3(256), 0, st, gout, gin, IH, IW, OH, OW, vpc, sy, sx);
+  else hipLaunchKernelGGL(bilinear_resize_adjoint_kernel<bf16_t>, grid, dim3(256), 0, st, gout, gin, IH, IW, OH, OW, vpc, sy, sx);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ ReLU of a plain tensor (PSPBlock with pool_size 1: biased conv, no BatchNorm), and its gradient
+// fwd: out = max(in, 0) (NaN propagates);  bwd (mask = the forward's OUTPUT): gin = gout where out > 0
+template <typename T>
+__global__ __launch_bounds__(256) void relu_kernel(const void* in, const void* mask, void* out, size_t nvec) {
+  constexpr int VEC = EV<T>::VEC;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    float f[VEC], m[VEC];
+    EV<T>::unpack(ldv<T>(in, v), f);
+    if (mask != nullptr) {
+      EV<T>::unpack(ldv<T>(mask, v), m);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) f[i] = m[i] > 0.f ? f[i] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) f[i] = f[i] < 0.f ? 0.f : f[i];
+    }
+    stv<T>(out, v, EV<T>::pack(f));
+  }
+}
+hipError_t launch_relu(int dtype, const void* in, const void* mask, void* out, size_t numel, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (numel % vec != 0) return hipErrorInvalidValue;
+  DL_DISPATCH(relu_kernel, dim3(grid_for(numel / vec, 256)), in, mask, out, numel / vec);
   return hipGetLastError();
 }
 

@@ -193,6 +193,12 @@ hipError_t launch_image_sum(int dtype, const void* in, void* out, int N, int HW,
 hipError_t launch_image_bcast(int dtype, const void* in, void* out, int N, int HW, int C, float scale, int accum, hipStream_t st);              // out [N][HW][C] (+)= scale * in [N][C]
 hipError_t launch_drop_elem(int dtype, const void* in, const float* keep, float mscale, void* out, size_t numel, hipStream_t st);                // out = in * keep * mscale
 hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H, int W, int C, int up, hipStream_t st);                         // NHWC, align_corners=True
+// ---- PSPNet (deeplab.hip)
+hipError_t launch_bin_mean(int dtype, const void* in, void* out, int N, int H, int W, int C, int k, hipStream_t st);                              // AdaptiveAvgPool2d((k, k)): out [N][k][k][C]
+hipError_t launch_bin_mean_bwd(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int k, int accum, hipStream_t st);
+hipError_t launch_bilinear_resize(int dtype, const void* in, void* out, int N, int IH, int IW, int OH, int OW, int C, hipStream_t st);          // align_corners=True, any sizes
+hipError_t launch_bilinear_resize_adjoint(int dtype, const void* gout, void* gin, int N, int IH, int IW, int OH, int OW, int C, hipStream_t st);
+hipError_t launch_relu(int dtype, const void* in, const void* mask, void* out, size_t numel, hipStream_t st);                                   // mask == nullptr: max(in, 0); else in where mask > 0
 
 // serving: out[n][y][x][out_ch] = (logits[n][ch] nearest-resized to OH x OW) > 0, out has OC channels per pixel
 hipError_t launch_mask_assemble(const float* logits, int N, int C, int SH, int SW, int ch, float* out, int OH, int OW, int OC, int out_ch,

@@ -362,6 +362,38 @@ struct Builder {
     P->ops.push_back(op);
     return o;
   }
+  // ---- PSPNet pieces (smp decoders/pspnet, restated in oracle/nets.py)
+  int binpool(int in, int k) {            // nn.AdaptiveAvgPool2d((k, k))
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, k, k, t.C);
+    Op op; op.kind = OP_BINPOOL; op.in = in; op.out = o; op.up = k;
+    P->ops.push_back(op);
+    return o;
+  }
+  int resize(int in, int H, int W) {      // F.interpolate(size=(H, W), mode='bilinear', align_corners=True)
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, H, W, t.C);
+    Op op; op.kind = OP_RESIZE; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int relu(int in) {
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_RELU; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int drop2d(int in) {                    // nn.Dropout2d, keep pattern [N][C] injected
+    const TensorInfo& t = P->tensors[in];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_DROP2D; op.in = in; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  // parameters and buffers of a layer the graph never runs (smp's get_encoder(depth=3) keeps layer3 / layer4 in the module and in state_dict)
+  void dead_conv(const std::string& name, int Cout, int Cin, int R) { param(name + ".weight", OCTSEG_P_CONV, R, R, Cout, Cin, 0); }
+  void dead_bn(const std::string& name, int C, int any_tensor) { bn(name, C, any_tensor, false); }
   int merge4(const int (&ins)[4]) {   // MergeBlock('add') + Dropout2d: every summand receives the same gradient -> one shared buffer
     const TensorInfo& t = P->tensors[ins[0]];
     const int o = tensor(t.N, t.H, t.W, t.C);
@@ -377,7 +409,8 @@ Value mat(int t) { Value v; v.t = t; v.bn = -1; return v; }
 // torchvision ResNet; returns materialised features f1..f5
 // dilate4: smp's make_dilated(output_stride=16) -- every conv of layer4 at stride 1 / dilation 2.  Built as the ordinary layer4 (stride 1)
 // on the parity re-arrangement of layer3's output (deeplab.hip header): no dilated conv kernel exists or is needed.
-std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 = false) {
+// depth: smp encoder_depth (5, or 3 for PSPNet: layer3 / layer4 keep their parameters and buffers but no op).
+std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 = false, int depth = 5) {
   octseg_plan* P = b.P;
   const bool bottleneck = enc == "resnet50" || enc == "resnet101" || enc == "resnet152";
   int nblocks[4];
@@ -399,6 +432,24 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 =
     const int planes = planes_l[li];
     const int exp = bottleneck ? 4 : 1;
     const bool dil = dilate4 && li == 3;
+    if (li + 2 > depth) {               // a stage behind the last feature the decoder reads: parameters only
+      for (int bi = 0; bi < nblocks[li]; ++bi) {
+        const int stride = (bi == 0 && li > 0) ? 2 : 1;
+        const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+        const bool ds = (stride != 1) || (inplanes != planes * exp);
+        if (!bottleneck) {
+          b.dead_conv(pre + ".conv1", planes, inplanes, 3); b.dead_bn(pre + ".bn1", planes, x);
+          b.dead_conv(pre + ".conv2", planes, planes, 3); b.dead_bn(pre + ".bn2", planes, x);
+        } else {
+          b.dead_conv(pre + ".conv1", planes, inplanes, 1); b.dead_bn(pre + ".bn1", planes, x);
+          b.dead_conv(pre + ".conv2", planes, planes, 3); b.dead_bn(pre + ".bn2", planes, x);
+          b.dead_conv(pre + ".conv3", planes * 4, planes, 1); b.dead_bn(pre + ".bn3", planes * 4, x);
+        }
+        if (ds) { b.dead_conv(pre + ".downsample.0", planes * exp, inplanes, 1); b.dead_bn(pre + ".downsample.1", planes * exp, x); }
+        inplanes = planes * exp;
+      }
+      continue;
+    }
     if (dil) x = b.parity(x, true);
     for (int bi = 0; bi < nblocks[li]; ++bi) {
       const int stride = (bi == 0 && li > 0 && !dil) ? 2 : 1;
@@ -510,7 +561,8 @@ static void assign_lanes(octseg_plan* P) {
 
 static int build_plan(octseg_plan* P) {
   Builder b{P, dtype_size(P->dtype)};
-  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus");  // f[0]=f1 .. f[4]=f5
+  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus", P->arch == "pspnet" ? 3 : 5);  // f[0]=f1 .. f[4]=f5
+  while (f.size() < 5) f.push_back(f.back());       // (PSPNet: three features; the slots of the others are never read)
   std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
   std::vector<int> ench;
   for (int t : fr) ench.push_back(P->tensors[t].C);
@@ -586,6 +638,27 @@ static int build_plan(octseg_plan* P) {
       seg[i] = t;
     }
     x = mat(b.merge4(seg));
+  } else if (P->arch == "pspnet") {
+    // smp PSPNet (reference sweep, configs/tune.yaml:9-18) with its defaults: encoder_depth 3 (the stride-8 feature), pyramid pooling to
+    // 1 / 2 / 3 / 6 bins, 1x1 conv to 512 + BN + ReLU, Dropout2d(0.2), 3x3 head + UpsamplingBilinear2d(8)
+    head_k = 3;
+    P->head_up = 8;
+    P->dropout_p = 0.2f;
+    const int X = f[2];
+    const TensorInfo tx = P->tensors[X];
+    const int sizes[4] = {1, 2, 3, 6};
+    std::vector<ConvSrc> cat;
+    for (int i = 0; i < 4; ++i) {
+      const std::string pre = "decoder.psp.blocks." + std::to_string(i) + ".pool.1";
+      const int g = b.binpool(X, sizes[i]);
+      int a;
+      if (sizes[i] == 1) a = b.relu(b.conv(pre + ".0", {{mat(g), 0}}, tx.C / 4, 1, 1, 0, "", true).t);      // no BatchNorm on a 1x1 map: biased conv
+      else a = b.bn_act(b.conv(pre + ".0", {{mat(g), 0}}, tx.C / 4, 1, 1, 0, pre + ".1", false), Value(), -1, true);
+      cat.push_back({mat(b.resize(a, tx.H, tx.W)), 0});
+    }
+    cat.push_back({mat(X), 0});
+    const Value v = b.conv("decoder.conv.0", cat, 512, 1, 1, 0, "decoder.conv.1", false);
+    x = mat(b.drop2d(b.bn_act(v, Value(), -1, true)));
   } else if (P->arch == "deeplabv3plus") {
     // smp DeepLabV3Plus (reference sweep, configs/tune.yaml:9-18) with its defaults: encoder_output_stride 16, decoder_channels 256,
     // atrous rates (12, 24, 36), 48-channel high-resolution branch from the stride-4 feature, head = 1x1 conv + UpsamplingBilinear2d(4).
@@ -627,12 +700,12 @@ static int build_plan(octseg_plan* P) {
     b.dw(hm, t2, 256, wp2, 256, 1);
     x = b.conv("decoder.block2.0.1", {{mat(t2), 0}}, 256, 1, 1, 0, "decoder.block2.1", false);
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | pspnet)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (P->arch != "fpn" && P->arch != "deeplabv3plus") assign_lanes(P);
+  if (P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -1078,6 +1151,30 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         HIPCHK(launch_bilinear_up(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, op.up, st));
         break;
       }
+      case OP_BINPOOL: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_bin_mean(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, op.up, st));
+        break;
+      }
+      case OP_RESIZE: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        HIPCHK(launch_bilinear_resize(P->dtype, E.act(op.in), E.act(op.out), ti.N, ti.H, ti.W, to.H, to.W, ti.C, st));
+        break;
+      }
+      case OP_RELU: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_relu(P->dtype, E.act(op.in), nullptr, E.act(op.out), (size_t)t.N * t.H * t.W * t.C, st));
+        break;
+      }
+      case OP_DROP2D: {
+        const TensorInfo& t = P->tensors[op.out];
+        if (E.train && P->dropout_keep == nullptr)
+          return fail(OCTSEG_BAD_ARG, "PSPNet training forward: no Dropout2d keep mask set (octseg_plan_set_dropout: device float [B][512] of 0 / 1)");
+        if (E.train) HIPCHK(launch_drop_bwd(P->dtype, E.act(op.in), P->dropout_keep, 1.0f / (1.0f - P->dropout_p), E.act(op.out), t.N, (size_t)t.H * t.W, t.C, st));
+        else HIPCHK(launch_drop_elem(P->dtype, E.act(op.in), nullptr, 1.f, E.act(op.out), (size_t)t.N * t.H * t.W * t.C, st));   // eval: identity (copy)
+        break;
+      }
       case OP_UPLOGITS: {
         const int h4 = P->H / P->head_up, w4 = P->W / P->head_up;
         HIPCHK(launch_bilinear_nchw((const float*)(E.ws + P->z4_off), logits, P->B * P->classes, h4, w4, P->head_up, st));
@@ -1390,6 +1487,31 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
           const int acc = E.claim(op.post);
           HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), G, nullptr, n, acc ? 0 : 1, E.st));
         }
+        break;
+      }
+      case OP_DROP2D: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_drop_bwd(P->dtype, E.grad(op.out), P->dropout_keep, 1.0f / (1.0f - P->dropout_p), E.grad(op.in), t.N, (size_t)t.H * t.W, t.C, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_RELU: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_relu(P->dtype, E.grad(op.out), E.act(op.out), E.grad(op.in), (size_t)t.N * t.H * t.W * t.C, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_RESIZE: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        HIPCHK(launch_bilinear_resize_adjoint(P->dtype, E.grad(op.out), E.grad(op.in), ti.N, ti.H, ti.W, to.H, to.W, ti.C, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_BINPOOL: {
+        const TensorInfo& t = P->tensors[op.in];
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_bin_mean_bwd(P->dtype, E.grad(op.out), E.grad(op.in), t.N, t.H, t.W, t.C, op.up, acc, E.st));
         break;
       }
       case OP_UPB: {

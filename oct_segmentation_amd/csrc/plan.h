@@ -80,7 +80,12 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               OP_GAP,        // out [N][1][1][C] = mean over the pixels of in (AdaptiveAvgPool2d(1))
               OP_BCAST,      // out [N][H][W][C] = in [N][1][1][C] (bilinear resize of a 1x1 map)
               OP_DROPE,      // out = in * element-wise dropout keep mask / (1 - p)
-              OP_UPB };      // out = bilinear x up of in (align_corners=True)
+              OP_UPB,        // out = bilinear x up of in (align_corners=True)
+              // PSPNet (deeplab.hip)
+              OP_BINPOOL,    // out [N][k][k][C] = AdaptiveAvgPool2d((k, k)) of in, k = up
+              OP_RESIZE,     // out = bilinear resize of in to out's size (align_corners=True)
+              OP_RELU,       // out = relu(in) of a plain tensor (biased conv without BatchNorm)
+              OP_DROP2D };   // out = in * Dropout2d keep pattern [N][C] / (1 - p)
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV

@@ -16,9 +16,10 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet')
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
+_PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
 _ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152')
 
 
@@ -161,8 +162,10 @@ class SegNet(nn.Module):
                      'decoder_pyramid_channels': 256, 'decoder_segmentation_channels': 128, 'decoder_merge_policy': 'add',
                      'decoder_dropout': 0.2, 'upsampling': 4,
                      # smp.DeepLabV3Plus's own keywords, at their defaults (decoder_channels: see _ARCH_DEFAULTS)
-                     'encoder_output_stride': 16, 'decoder_atrous_rates': (12, 24, 36)}
-    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}}
+                     'encoder_output_stride': 16, 'decoder_atrous_rates': (12, 24, 36),
+                     # smp.PSPNet's own keywords, at their defaults (encoder_depth, upsampling: see _ARCH_DEFAULTS)
+                     'psp_out_channels': 512, 'psp_use_batchnorm': True, 'psp_dropout': 0.2}
+    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8}}
 
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
                  device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
@@ -192,7 +195,8 @@ class SegNet(nn.Module):
         # launches of a step cost the host tens of milliseconds to enqueue, which bounds small per-GPU batches; not with `exchange`
         self.use_train_graph = use_train_graph
         # arch 'fpn': nn.Dropout2d(0.2) sits behind the merge; arch 'deeplabv3plus': nn.Dropout(0.5) behind ASPP.project.  Training
-        # forwards draw a keep pattern on the device (torch's RNG, as the reference's modules do) -- [B, 128] per channel for FPN,
+        # forwards draw a keep pattern on the device (torch's RNG, as the reference's modules do) -- [B, 128] per channel for FPN
+        # ([B, 512] for PSPNet's Dropout2d(0.2)),
         # [B, H/16, W/16, 256] NHWC per element for DeepLabV3+ -- unless `dropout_keep` holds one (tests inject the oracle's;
         # DeepLabV3+ also accepts torch's NCHW [B, 256, H/16, W/16]); eval ignores it.
         self.dropout_keep = None
@@ -392,11 +396,13 @@ class SegNet(nn.Module):
         return x.contiguous()
 
     def _has_dropout(self):
-        return self.arch in ('fpn', 'deeplabv3plus')
+        return self.arch in ('fpn', 'deeplabv3plus', 'pspnet')
 
     def _keep_shape(self, B, H, W):
         if self.arch == 'fpn':
             return (B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT
+        if self.arch == 'pspnet':
+            return (B, _PSP_CHANNELS), 1.0 - _PSP_DROPOUT
         return (B, H // 16, W // 16, _DLV3P_CHANNELS), 1.0 - _DLV3P_DROPOUT
 
     def _draw_keep(self, B, H, W, device):

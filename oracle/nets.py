@@ -91,11 +91,12 @@ class Bottleneck(nn.Module):
 class ResNetEncoder(nn.Module):
     """torchvision ResNet minus avgpool/fc, returning the 6 smp features."""
 
-    def __init__(self, name, in_channels=3):
+    def __init__(self, name, in_channels=3, depth=5):
         super().__init__()
+        self._depth = depth            # smp get_encoder(depth=...): the stages stay in the module (and in state_dict), forward stops early
         kind, layers = _RESNET_CFG[name]
         block = BasicBlock if kind == 'basic' else Bottleneck
-        self.out_channels = ENCODER_CHANNELS[name]
+        self.out_channels = ENCODER_CHANNELS[name][:depth + 1]
         self.inplanes = 64
         self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -144,13 +145,11 @@ class ResNetEncoder(nn.Module):
                     m.padding = ((kh // 2) * rate, (kw // 2) * rate)
 
     def forward(self, x):
-        f0 = x
-        f1 = self.relu(self.bn1(self.conv1(x)))
-        f2 = self.layer1(self.maxpool(f1))
-        f3 = self.layer2(f2)
-        f4 = self.layer3(f3)
-        f5 = self.layer4(f4)
-        return [f0, f1, f2, f3, f4, f5]
+        feats = [x, self.relu(self.bn1(self.conv1(x)))]
+        stages = [lambda t: self.layer1(self.maxpool(t)), self.layer2, self.layer3, self.layer4]
+        for stage in stages[:self._depth - 1]:
+            feats.append(stage(feats[-1]))
+        return feats
 
 
 class Conv2dReLU(nn.Sequential):
@@ -452,6 +451,46 @@ class DeepLabV3PlusDecoder(nn.Module):
         return self.block2(torch.cat([a, hi], dim=1))
 
 
+class PSPBlock(nn.Module):
+    """smp decoders/pspnet/decoder.py PSPBlock: adaptive average pooling to pool_size^2 bins, 1x1 Conv2dReLU (BatchNorm unless pool_size is
+    1 -- then a biased conv), bilinear resize back (align_corners=True)."""
+
+    def __init__(self, cin, cout, pool_size, use_batchnorm=True):
+        super().__init__()
+        if pool_size == 1:
+            use_batchnorm = False
+        conv = nn.Conv2d(cin, cout, 1, bias=not use_batchnorm)
+        self.pool = nn.Sequential(nn.AdaptiveAvgPool2d((pool_size, pool_size)),
+                                  nn.Sequential(conv, nn.BatchNorm2d(cout) if use_batchnorm else nn.Identity(), nn.ReLU(inplace=True)))
+
+    def forward(self, x):
+        h, w = x.shape[-2:]
+        return F.interpolate(self.pool(x), size=(h, w), mode='bilinear', align_corners=True)
+
+
+class PSPModule(nn.Module):
+    def __init__(self, cin, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.blocks = nn.ModuleList([PSPBlock(cin, cin // len(sizes), s) for s in sizes])
+
+    def forward(self, x):
+        return torch.cat([b(x) for b in self.blocks] + [x], dim=1)
+
+
+class PSPDecoder(nn.Module):
+    """smp PSPDecoder: pyramid pooling on the LAST encoder feature (encoder_depth 3: stride 8), 1x1 Conv2dReLU to 512, Dropout2d(0.2)."""
+
+    def __init__(self, encoder_channels, out_channels=512, dropout=0.2):
+        super().__init__()
+        self.out_channels = out_channels
+        self.psp = PSPModule(encoder_channels[-1])
+        self.conv = nn.Sequential(nn.Conv2d(encoder_channels[-1] * 2, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+        self.dropout = InjectableDropout2d(dropout)
+
+    def forward(self, *features):
+        return self.dropout(self.conv(self.psp(features[-1])))
+
+
 class SegmentationHead(nn.Sequential):
     def __init__(self, cin, cout, kernel_size, upsampling=1):
         super().__init__(
@@ -483,7 +522,7 @@ def _init_head(module):
 class SegmentationModel(nn.Module):
     def __init__(self, arch, encoder_name, in_channels, classes):
         super().__init__()
-        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.encoder = ResNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)
         ch = self.encoder.out_channels
         if arch == 'unet':
             self.decoder = UnetDecoder(ch)
@@ -497,6 +536,10 @@ class SegmentationModel(nn.Module):
         elif arch == 'fpn':
             self.decoder = FPNDecoder(ch)
             self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 1, upsampling=4)
+        elif arch == 'pspnet':
+            # smp PSPNet defaults: encoder_depth=3, psp_out_channels=512, psp_use_batchnorm=True, psp_dropout=0.2, upsampling=8, 3x3 head
+            self.decoder = PSPDecoder(ch)
+            self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 3, upsampling=8)
         elif arch == 'deeplabv3plus':
             # smp DeepLabV3Plus defaults: encoder_output_stride=16, decoder_channels=256, decoder_atrous_rates=(12, 24, 36), upsampling=4
             self.encoder.make_dilated(16)
@@ -516,7 +559,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):

@@ -35,6 +35,7 @@ CASES = {
     # the sweep architectures of round 3; their dropout keep patterns are derived from the seed (case_keep)
     'fpn_resnet18_64x96': ('fpn', 'resnet18', 2, 2, (64, 96), 140),
     'deeplabv3plus_resnet18_64x96': ('deeplabv3plus', 'resnet18', 2, 4, (64, 96), 141),
+    'pspnet_resnet18_96x64': ('pspnet', 'resnet18', 2, 3, (96, 64), 142),
 }
 # Lightning-DDP semantics (reference train.py:122-133 with devices > 1): the global batch is split
 # into `world` contiguous shards, every rank runs forward + Dice + backward on ITS shard with local BatchNorm statistics
@@ -59,18 +60,20 @@ def case_batch(B, classes, S, seed, arch=None):
         img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
     else:
         img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
-    if arch == 'deeplabv3plus':
+    if arch in ('deeplabv3plus', 'pspnet'):
         img = (img * (0.35 + 0.65 * torch.arange(B).view(B, 1, 1, 1) / max(1, B - 1))).round().contiguous()
     return img, mask
 
 
 def case_keep(arch, B, S, seed):
     """Dropout keep pattern of a case in torch's layout: FPN Dropout2d [B, 128] (p = 0.2), DeepLabV3+ element-wise [B, 256, H/16, W/16]
-    (p = 0.5); None for the architectures without dropout."""
+    (p = 0.5), PSPNet Dropout2d [B, 512] (p = 0.2); None for the architectures without dropout."""
     H, W = S if isinstance(S, tuple) else (S, S)
     g = torch.Generator().manual_seed(seed + 2)
     if arch == 'fpn':
         return (torch.rand(B, 128, generator=g) < 0.8).float()
+    if arch == 'pspnet':
+        return (torch.rand(B, 512, generator=g) < 0.8).float()
     if arch == 'deeplabv3plus':
         return (torch.rand(B, 256, H // 16, W // 16, generator=g) < 0.5).float()
     return None
@@ -101,7 +104,7 @@ def build(arch, enc, classes, seed, kinkfree=True):
             for mod in m.modules():
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.bias.copy_(8.0 * ((torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1))
-            if arch in ('fpn', 'deeplabv3plus'):
+            if arch in ('fpn', 'deeplabv3plus', 'pspnet'):
                 # their heads sit straight behind normalisation layers with +-8 biases (summed four times in FPN): keep |logits| of order 1,
                 # a saturated sigmoid has no gradient to compare
                 for mod in m.modules():
@@ -125,7 +128,7 @@ def run_case(arch, enc, classes, B, S, seed):
     loss.backward()
     tp, fp, fn, tn = get_stats((logits.detach().sigmoid() > 0.5).long(), mask.long())
     return {'logits': logits.detach().numpy(), 'loss': float(loss.item()),
-            'grad_abs_sums': np.array([p.grad.abs().sum().item() for _, p in m.named_parameters()], dtype=np.float64),
+            'grad_abs_sums': np.array([0.0 if p.grad is None else p.grad.abs().sum().item() for _, p in m.named_parameters()], dtype=np.float64),
             'stats': torch.stack([tp, fp, fn, tn], dim=-1).numpy()}
 
 

@@ -92,8 +92,9 @@ def judge_gradients(ref, grads, img, mask, tag=''):
     re-judged parameters."""
     import copy
     from oracle import DiceLoss
-    gmax = max(p.grad.abs().max().item() for _, p in ref.named_parameters())
-    rel = {n: (grads[n].cpu() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax) for n, p in ref.named_parameters()}
+    live = [(n, p) for n, p in ref.named_parameters() if p.grad is not None]     # (PSPNet: the encoder stages that never run have none)
+    gmax = max(p.grad.abs().max().item() for _, p in live)
+    rel = {n: (grads[n].cpu() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-3 * gmax) for n, p in live}
     loose = sorted(n for n, e in rel.items() if e >= 2e-3)
     if not loose:
         return 0

@@ -1,4 +1,4 @@
-"""Seeded fuzz over the sweep architectures added in round 3 (FPN, DeepLabV3+): random encoder x batch x classes x
+"""Seeded fuzz over the sweep architectures added in round 3 (FPN, DeepLabV3+, PSPNet): random encoder x batch x classes x
 non-square frame, kink-free normalisation biases (so that fp32 implementations agree on every ReLU mask), the oracle's dropout pattern
 injected.  Bounds of the per-architecture tests: logits 1e-4 of their scale (2e-4 behind the 50+-layer encoders), Dice 1e-5, counts exact,
 gradient cosine 1 - 1e-6, every parameter within 2e-3 of its largest element or re-judged against float64 (test_gpu_deeplab.judge_gradients).
@@ -10,11 +10,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _cases(n=10, seed=2024):
+def _cases(n=15, seed=2024):
     rng = np.random.default_rng(seed)
     out = []
     for k in range(n):
-        arch = ['fpn', 'deeplabv3plus'][k % 2]
+        arch = ['fpn', 'deeplabv3plus'][k % 2] if k < 10 else 'pspnet'    # (PSPNet cases appended: the first ten keep their draws)
         enc = ['resnet18', 'resnet34', 'resnet50', 'resnet101'][rng.integers(4)]
         B = int(rng.integers(2, 5)) if arch == 'fpn' else int(rng.integers(3, 5))
         classes = int(rng.integers(1, 4))
@@ -27,14 +27,14 @@ def _cases(n=10, seed=2024):
 def test_fuzz_f4_fp32(cuda, case):
     from oracle import get_stats
     from test_gpu_net import _grad_report
-    import test_gpu_deeplab, test_gpu_fpn
+    import test_gpu_deeplab, test_gpu_fpn, test_gpu_pspnet
     k, arch, enc, B, classes, H, W = case
-    pair = test_gpu_fpn._pair if arch == 'fpn' else test_gpu_deeplab._pair
+    pair = {'fpn': test_gpu_fpn._pair, 'deeplabv3plus': test_gpu_deeplab._pair, 'pspnet': test_gpu_pspnet._pair}[arch]
     ref, net, img, mask, z, loss_ref, logits, loss, stats = pair(cuda, enc, classes, B, H, W, seed=100 + k, kinkfree=True)
     scale = z.abs().max().item()
     err = (logits - z).abs().max().item()
     grads = net.named_grads()
-    cos, worst, name = _grad_report(grads, ref)
+    cos, worst, name = test_gpu_pspnet._report(grads, ref) if arch == 'pspnet' else _grad_report(grads, ref)
     print(f'k={k} {arch}/{enc} B={B} C={classes} {H}x{W}: logits {err:.1e}/{scale:.2f} loss {abs(loss.item() - loss_ref.item()):.1e} cos {cos:.9f} worst {worst:.1e} ({name})')
     assert err <= (2e-4 if enc in ('resnet50', 'resnet101') else 1e-4) * max(1.0, scale)
     assert abs(loss.item() - loss_ref.item()) <= 1e-5

@@ -41,7 +41,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
   float* image = (float*)carve(px * 3 * 4); float* logits = (float*)carve(px * d.classes * 4); float* target = (float*)carve(px * d.classes * 4);
   float* loss = (float*)carve(4); long long* stats = (long long*)carve((size_t)d.batch * d.classes * 4 * 8);
   const bool dl = !strcmp(d.arch, "deeplabv3plus");   // fpn: Dropout2d pattern [B][128]; deeplabv3plus: element-wise [B][H/16][W/16][256]
-  float* keep = (float*)carve(dl ? (size_t)d.batch * (d.height / 16) * (d.width / 16) * 256 * 4 : (size_t)d.batch * 128 * 4);
+  float* keep = (float*)carve(dl ? (size_t)d.batch * (d.height / 16) * (d.width / 16) * 256 * 4 : (size_t)d.batch * 512 * 4);   // (pspnet: [B][512])
   octseg_plan_set_dropout(p, keep);                 // (ignored by the other architectures)
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   void* st = (void*)(uintptr_t)0x4000; void* comm = (void*)(uintptr_t)0x4100;
@@ -82,7 +82,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 }  // namespace
 
 int main() {
-  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus"};
+  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet"};
   const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
@@ -143,7 +143,7 @@ int main() {
           }
   // shapes the builder must refuse (smp check_input_shape / argument checks) without touching memory it does not own
   octseg_plan* q = nullptr;
-  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"pspnet", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
+  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"manet", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
       bad4{"unet", "resnet18", 0, 1, 32, 32, 0}, bad5{"unet", "resnet18", 1, 1, 32, 32, 7};
   for (octseg_net_desc* b : {&bad1, &bad2, &bad3, &bad4, &bad5})
     if (octseg_plan_create(b, &q) == 0) { fprintf(stderr, "a bad descriptor was accepted\n"); return 7; }
