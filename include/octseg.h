@@ -61,7 +61,7 @@ typedef enum {
 typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
-  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" (case-insensitive) */
+  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" | "pspnet" (case-insensitive) */
   const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
   int classes;          /* output channels */
   int batch, height, width;
@@ -127,7 +127,10 @@ int octseg_plan_params_changed(octseg_plan* plan);
 /* arch "deeplabv3plus" (smp DeepLabV3Plus at its defaults: encoder_output_stride 16, decoder_channels 256, atrous rates (12, 24, 36);
  * same sweep, same call): the keep pattern is per ELEMENT of ASPP.project's output -- device float [batch][H/16][W/16][256] (NHWC) of
  * 0 / 1, kept elements scaled by 1 / (1 - 0.5).  A training forward with batch 1 fails like torch does ("Expected more than 1 value per
- * channel when training": the pooled ASPP branch's BatchNorm). */
+ * channel when training": the pooled ASPP branch's BatchNorm).
+ * arch "pspnet" (smp PSPNet at its defaults: encoder_depth 3, psp_out_channels 512, upsampling 8): Dropout2d(0.2) behind the fuse conv,
+ * device float [batch][512] of 0 / 1.  Its parameter table still lists encoder.layer3 / layer4 (smp keeps them in state_dict): they
+ * never run and their gradients are zero. */
 int octseg_plan_set_dropout(octseg_plan* plan, const float* keep_dev);
 
 /* Serving path (reference: src/models/smp/predict.py segment(), model.py:183-200 predict()): enable = 1 makes every
