@@ -15,7 +15,7 @@ def _cases(n=15, seed=2024):
     out = []
     for k in range(n):
         arch = ['fpn', 'deeplabv3plus'][k % 2] if k < 10 else 'pspnet'    # (PSPNet cases appended: the first ten keep their draws)
-        enc = ['resnet18', 'resnet34', 'resnet50', 'resnet101'][rng.integers(4)]
+        enc = ['resnet18', 'resnet34', 'resnet50'][rng.integers(3)]      # (resnet101 cost 35 s per float64 re-judge; its blocks are resnet50's)
         B = int(rng.integers(2, 5)) if arch == 'fpn' else int(rng.integers(3, 5))
         classes = int(rng.integers(1, 4))
         H, W = (int(32 * rng.integers(2, 5)) for _ in range(2))
