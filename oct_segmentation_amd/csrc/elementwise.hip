@@ -454,6 +454,57 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Small tensors (<= BN_SMALL_COUNT values per channel): reduction AND finalize in one launch, accumulated in double as torch's CPU
+// kernels do (acc_type).  sum dz * xhat is a sum of cancelling terms; with float partial sums the coefficients carry ~1e-6 of the
+// term size, which the apply pass (dz - c0 - xhat * c1, another cancellation) turns into 1e-3 .. 1e-2 of a small gradient on
+// 2x2 .. 8x8 maps (found by tests/test_gpu_fuzz_f4.py).  Block = 32 channels x 32 row lanes; same masking as bn_bwd_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnBwdArgs a) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ double red[32][33][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool live = c < a.C;
+  auto val = [&](const void* p, size_t i) -> float {
+    if (sizeof(T) == 4) return ((const float*)p)[i];
+    return __uint_as_float((unsigned)((const unsigned short*)p)[i] << 16);
+  };
+  double s1 = 0.0, s2 = 0.0;
+  if (live) {
+    const float sc = a.scale[c], sh = a.shift[c];
+    const double mu = (double)a.mean[c], rs = (double)a.rstd[c];
+    const int vpc = a.C / VEC, cv = c / VEC, ci = c - cv * VEC;
+    for (size_t p = rl; p < a.npix; p += 32) {
+      const size_t e = p * a.C + c;
+      float g = val(a.g, e);
+      const float y = val(a.y, e);
+      if (a.mask == 2) {
+        if (a.maskbits != nullptr) { if (!((a.maskbits[p * vpc + cv] >> ci) & 1u)) g = 0.f; }
+        else if (!(val(a.out, e) > 0.f)) g = 0.f;
+      } else if (a.mask == 1) {
+        if (!(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+      }
+      s1 += (double)g;
+      s2 += (double)g * (((double)y - mu) * rs);
+    }
+  }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (!live || rl != 0) return;
+  for (int k = 1; k < 32; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+  a.dbeta[c] += (float)s1;
+  a.dgamma[c] += (float)s2;
+  a.coef[2 * c] = (float)(s1 / (double)a.npix);
+  a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
+}
+hipError_t launch_bn_bwd_small(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  const dim3 grid((a.C + 31) / 32);
+  if (dtype == DT_F32) hipLaunchKernelGGL(bn_bwd_small_kernel<float>, grid, dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(bn_bwd_small_kernel<bf16_t>, grid, dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const BnBwdArgs a, const int cpb) {
   double s1, s2;
   int c;

@@ -111,6 +111,7 @@ struct BnBwdArgs {
   double* fpart; unsigned* fcnt;         // pass 1 finishing the reduction itself (no finalize launch): [8][32][4096] partials, [8][33][32] zeroed tickets (one 128-byte line each)
 };                                       // (what masked_accum would re-read g and the mask source for); res_store = 1: first writer
 
+hipError_t launch_bn_bwd_small(int dtype, const BnBwdArgs& a, hipStream_t st);   // reduce + finalize of a small tensor in one launch, double accumulation
 bool bn_bwd_fused_finalize();            // (opt-in switch OCTSEG_FUSED_BNFIN=1: measured slower than the separate launch)
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);   // a.fpart && a.fcnt: also does what launch_bn_bwd_finalize does
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st);

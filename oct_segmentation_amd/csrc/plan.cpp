@@ -1231,11 +1231,16 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   if (fused_fin) { a.fpart = (double*)(E.ws + P->bwd_part_off); a.fcnt = (unsigned*)(E.ws + P->bwd_cnt_off); }
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
-  {
+  if (a.npix <= (size_t)BN_SMALL_COUNT) {   // small tensors: one launch, double accumulation (elementwise.hip)
     ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 3 : 2), E.st, b.name + ".bwd_reduce");
-    HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
+    HIPCHK(launch_bn_bwd_small(P->dtype, a, E.st));
+  } else {
+    {
+      ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 3 : 2), E.st, b.name + ".bwd_reduce");
+      HIPCHK(launch_bn_bwd_reduce(P->dtype, a, E.st));
+    }
+    if (!fused_fin) HIPCHK(launch_bn_bwd_finalize(a, E.st));
   }
-  if (!fused_fin) HIPCHK(launch_bn_bwd_finalize(a, E.st));
   {
     ProfScope ps(3, tbytes * (((mask == 2 && !maskbits) ? 4 : 3) + (res_grad ? (res_store ? 1 : 2) : 0)), E.st, b.name + ".bwd_apply");
     HIPCHK(launch_bn_bwd_apply(P->dtype, a, E.st));
