@@ -310,10 +310,10 @@ hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H
 // (neighbouring bins overlap by a row / column when k does not divide H).  out [N][k][k][C]; grid (ceil(vpc / DW_CH), N k k), deterministic.
 static __device__ __forceinline__ void bin_range(int i, int k, int H, int& lo, int& hi) { lo = (i * H) / k; hi = ((i + 1) * H + k - 1) / k; }
 template <typename T>
-__global__ __launch_bounds__(256) void bin_mean_kernel(const void* in, void* out, int H, int W, int k, int vpc) {
+__global__ __launch_bounds__(256) void bin_mean_kernel(const void* in, void* out, int H, int W, int k, int vpc, int ch) {
   constexpr int VEC = EV<T>::VEC;
   __shared__ float red[256 * VEC];
-  const int v0 = blockIdx.x * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
+  const int v0 = blockIdx.x * ch, nv = min(ch, vpc - v0), rows = 256 / nv;   // ch channel vectors per block (few bins: narrow chunks, more pixel rows)
   const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
   const int bin = blockIdx.y % (k * k);
   const size_t n = blockIdx.y / (k * k);
@@ -349,7 +349,8 @@ hipError_t launch_bin_mean(int dtype, const void* in, void* out, int N, int H, i
   const int vec = dtype == DT_F32 ? 4 : 8;
   if (C % vec != 0 || k < 1) return hipErrorInvalidValue;
   const int vpc = C / vec;
-  DL_DISPATCH(bin_mean_kernel, dim3((vpc + DW_CH - 1) / DW_CH, N * k * k), in, out, H, W, k, vpc);
+  const int ch = N * k * k >= 256 ? DW_CH : 8;      // the 1x1 / 2x2 bins of a 16-frame batch are 16 / 64 blocks of up to 7744 pixels each
+  DL_DISPATCH(bin_mean_kernel, dim3((vpc + ch - 1) / ch, N * k * k), in, out, H, W, k, vpc, ch);
   return hipGetLastError();
 }
 // its gradient, gather form: gin[n][y][x] (+)= sum over the bins that contain (y, x) of gout[bin] / area(bin)
