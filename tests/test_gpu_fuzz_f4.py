@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _cases(n=15, seed=2024):
+def _cases(n=15, seed=2024, keep=(0, 1, 2, 3, 5, 7, 10, 12, 13)):
     rng = np.random.default_rng(seed)
     out = []
     for k in range(n):
@@ -20,7 +20,7 @@ def _cases(n=15, seed=2024):
         classes = int(rng.integers(1, 4))
         H, W = (int(32 * rng.integers(2, 5)) for _ in range(2))
         out.append((k, arch, enc, B, classes, H, W))
-    return out
+    return [c for c in out if c[0] in keep]      # three per architecture (the GPU suite's time budget); the draws of all 15 stay as they were
 
 
 @pytest.mark.parametrize('case', _cases(), ids=lambda c: f'{c[0]}-{c[1]}-{c[2]}-B{c[3]}-C{c[4]}-{c[5]}x{c[6]}')
