@@ -204,6 +204,8 @@ static hipError_t create_side_stream(hipStream_t* st) {
     if (e != hipSuccess) return e;
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest);
   }
+  // (a side stream confined to a share of the compute units -- hipExtStreamCreateWithCUMask, 6 / 4 / 7 of every 8 CUs -- so that the caller's
+  //  stream always finds free CUs for its sweeps: 75.2 -> 91.7 ms per step whatever the share; measured once, not kept)
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
