@@ -44,6 +44,7 @@ WORKLOADS = {
     'fpn_r50_704': ('fpn', 'resnet50', 1, 704),       # sweep architectures outside BASELINE's three
     'deeplabv3plus_r50_704': ('deeplabv3plus', 'resnet50', 1, 704),
     'pspnet_r50_704': ('pspnet', 'resnet50', 1, 704),
+    'deeplabv3_r50_704': ('deeplabv3', 'resnet50', 1, 704),
 }
 
 

@@ -61,7 +61,7 @@ typedef enum {
 typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
-  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" | "pspnet" (case-insensitive) */
+  const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" | "deeplabv3" | "pspnet" (case-insensitive) */
   const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
   int classes;          /* output channels */
   int batch, height, width;
@@ -128,6 +128,7 @@ int octseg_plan_params_changed(octseg_plan* plan);
  * same sweep, same call): the keep pattern is per ELEMENT of ASPP.project's output -- device float [batch][H/16][W/16][256] (NHWC) of
  * 0 / 1, kept elements scaled by 1 / (1 - 0.5).  A training forward with batch 1 fails like torch does ("Expected more than 1 value per
  * channel when training": the pooled ASPP branch's BatchNorm).
+ * arch "deeplabv3" (smp DeepLabV3 at its defaults: output stride 8, dense ASPP): as "deeplabv3plus" with [batch][H/8][W/8][256].
  * arch "pspnet" (smp PSPNet at its defaults: encoder_depth 3, psp_out_channels 512, upsampling 8): Dropout2d(0.2) behind the fuse conv,
  * device float [batch][512] of 0 / 1.  Its parameter table still lists encoder.layer3 / layer4 (smp keeps them in state_dict): they
  * never run and their gradients are zero. */

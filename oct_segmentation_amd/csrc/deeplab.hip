@@ -516,4 +516,98 @@ hipError_t launch_relu(int dtype, const void* in, const void* mask, void* out, s
   return hipGetLastError();
 }
 
+// ================================================================== DeepLabV3 (dense ASPP): dilation r, any rate, without a dilated kernel
+// A 3x3 conv with dilation r and padding r combines pixels of equal (y mod r, x mod r) only: on each of the r^2 sub-grids it is the plain
+// pad-1 3x3 conv.  For r = 12 / 24 / 36 the sub-grids of an 88 x 88 map are 8 x 8 .. 3 x 3 pixels -- far below a conv tile -- so they are
+// laid out as ONE mosaic image per frame instead of as a batch: sub-grid (a, b) occupies an hs x ws block at rows 1 + a (hs + 1), columns
+// 1 + b (ws + 1) (hs = ceil(H / r)), separated by one-pixel ZERO gutters, which are exactly the zero padding each sub-grid's conv needs.
+// A plain 3x3 / pad 1 conv over the (r (hs + 1) + 1)-square mosaic then computes every sub-grid at once; outputs on gutters and on the
+// padding behind H, W are discarded on the way back.  (BatchNorm statistics therefore come from tensor_stats on the fine tensor, not
+// from the conv's epilogue.)
+// to_mosaic: mosaic = fine re-arranged, zeros elsewhere (every mosaic element is written);  else: fine (+)= its mosaic element.
+template <typename T>
+__global__ __launch_bounds__(256) void mosaic_kernel(const void* src, void* dst, int N, int H, int W, int vpc, int r, int hs, int ws, int to_mosaic,
+                                                     int accum) {
+  constexpr int VEC = EV<T>::VEC;
+  const int MH = r * (hs + 1) + 1, MW = r * (ws + 1) + 1;
+  if (to_mosaic) {
+    const size_t nvec = (size_t)N * MH * MW * vpc;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+      const int cv = (int)(v % vpc);
+      size_t p = v / vpc;
+      const int mx = (int)(p % MW); p /= MW;
+      const int my = (int)(p % MH);
+      const size_t n = p / MH;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (my >= 1 && mx >= 1) {
+        const int a = (my - 1) / (hs + 1), i = (my - 1) - a * (hs + 1);
+        const int b = (mx - 1) / (ws + 1), j = (mx - 1) - b * (ws + 1);
+        const int y = i * r + a, x = j * r + b;
+        if (i < hs && j < ws && a < r && b < r && y < H && x < W) q = ldv<T>(src, ((n * H + y) * W + x) * vpc + cv);
+      }
+      stv<T>(dst, v, q);
+    }
+  } else {
+    const size_t nvec = (size_t)N * H * W * vpc;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+      const int cv = (int)(v % vpc);
+      size_t p = v / vpc;
+      const int x = (int)(p % W); p /= W;
+      const int y = (int)(p % H);
+      const size_t n = p / H;
+      const int my = 1 + (y % r) * (hs + 1) + y / r, mx = 1 + (x % r) * (ws + 1) + x / r;
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(src, ((n * MH + my) * MW + mx) * vpc + cv), f);
+      put<T>(dst, v, f, accum);
+    }
+  }
+}
+hipError_t launch_mosaic(int dtype, const void* src, void* dst, int N, int H, int W, int C, int r, int to_mosaic, int accum, hipStream_t st) {
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || r < 1) return hipErrorInvalidValue;
+  const int hs = (H + r - 1) / r, ws = (W + r - 1) / r;
+  const size_t nvec = to_mosaic ? (size_t)N * (r * (hs + 1) + 1) * (r * (ws + 1) + 1) * (C / vec) : (size_t)N * H * W * (C / vec);
+  DL_DISPATCH(mosaic_kernel, dim3(grid_for(nvec, 256)), src, dst, N, H, W, C / vec, r, hs, ws, to_mosaic, accum);
+  return hipGetLastError();
+}
+
+// BatchNorm partial sums of a plain NHWC tensor: slab[row][c] = (sum y, sum y^2) over the pixels row, row + rows, ... (the rows of
+// bn_finalize_train; for tensors whose producer is not a conv epilogue).  C / VEC <= 256 channel vectors.
+template <typename T>
+__global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t npix, int vpc, int C, float* slab) {
+  constexpr int VEC = EV<T>::VEC;
+  __shared__ float red[256][2 * VEC + 1];
+  const int tpv = 256 / vpc;
+  const int cv = threadIdx.x % vpc, pl = threadIdx.x / vpc;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (pl < tpv)
+    for (size_t p = (size_t)blockIdx.x * tpv + pl; p < npix; p += (size_t)gridDim.x * tpv) {
+      float f[VEC];
+      EV<T>::unpack(ldv<T>(y, p * vpc + cv), f);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
+    }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[threadIdx.x][i] = s1[i]; red[threadIdx.x][VEC + i] = s2[i]; }
+  __syncthreads();
+  if (pl == 0) {
+    for (int k = 1; k < tpv; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s1[i] += red[threadIdx.x + k * vpc][i]; s2[i] += red[threadIdx.x + k * vpc][VEC + i]; }
+    float* o = slab + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { o[2 * i] = s1[i]; o[2 * i + 1] = s2[i]; }
+  }
+}
+hipError_t launch_tensor_stats(int dtype, const void* y, size_t npix, int C, float* slab, int rows, hipStream_t st) {
+  OCTSEG_NO_F16(dtype);
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  if (C % vec != 0 || C / vec > 256 || rows < 1) return hipErrorInvalidValue;
+  if (dtype == DT_F32) hipLaunchKernelGGL(tensor_stats_kernel<float>, dim3(rows), dim3(256), 0, st, y, npix, C / vec, C, slab);
+  else hipLaunchKernelGGL(tensor_stats_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, y, npix, C / vec, C, slab);
+  return hipGetLastError();
+}
+
 }  // namespace octseg

@@ -454,10 +454,12 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Small tensors (<= BN_SMALL_COUNT values per channel): reduction AND finalize in one launch, accumulated in double as torch's CPU
-// kernels do (acc_type).  sum dz * xhat is a sum of cancelling terms; with float partial sums the coefficients carry ~1e-6 of the
-// term size, which the apply pass (dz - c0 - xhat * c1, another cancellation) turns into 1e-3 .. 1e-2 of a small gradient on
-// 2x2 .. 8x8 maps (found by tests/test_gpu_fuzz_f4.py).  Block = 32 channels x 32 row lanes; same masking as bn_bwd_reduce_kernel.
+// Small tensors (<= BN_SMALL_COUNT values per channel): reduction, finalize AND apply in one launch, all in double as torch's CPU
+// kernels do (acc_type: sums, k = dotp * invstd^2 / n and dx = (dy - mean_dy - (x - mean) k) invstd w are evaluated in double and
+// rounded once).  sum dz * xhat is a sum of cancelling terms and the apply pass another cancellation; in float the engine sat 80..500x
+// further from the float64 gradient than torch on 2x2 .. 8x8 maps (1e-2 of a small gradient; found by tests/test_gpu_fuzz_f4.py).
+// Block = 32 channels x 32 row lanes; a thread reads and writes its own rows only (dy may alias g); same masking and identity-shortcut
+// hand-off as bn_bwd_reduce_kernel / bn_bwd_apply_kernel.
 template <typename T>
 __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnBwdArgs a) {
   constexpr int VEC = EV<T>::VEC;
@@ -469,33 +471,51 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnBwdArgs a) {
     if (sizeof(T) == 4) return ((const float*)p)[i];
     return __uint_as_float((unsigned)((const unsigned short*)p)[i] << 16);
   };
+  auto put = [&](void* p, size_t i, float v) {
+    if (sizeof(T) == 4) ((float*)p)[i] = v;
+    else ((unsigned short*)p)[i] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+  };
+  const float sc = live ? a.scale[c] : 0.f, sh = live ? a.shift[c] : 0.f;
+  const double mu = live ? (double)a.mean[c] : 0.0, rs = live ? (double)a.rstd[c] : 0.0;
+  const int vpc = a.C / VEC, cv = c / VEC, ci = c - cv * VEC;
+  auto masked_g = [&](size_t p, size_t e, float y) -> float {
+    float g = val(a.g, e);
+    if (a.mask == 2) {
+      if (a.maskbits != nullptr) { if (!((a.maskbits[p * vpc + cv] >> ci) & 1u)) g = 0.f; }
+      else if (!(val(a.out, e) > 0.f)) g = 0.f;
+    } else if (a.mask == 1) {
+      if (!(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+    }
+    return g;
+  };
   double s1 = 0.0, s2 = 0.0;
-  if (live) {
-    const float sc = a.scale[c], sh = a.shift[c];
-    const double mu = (double)a.mean[c], rs = (double)a.rstd[c];
-    const int vpc = a.C / VEC, cv = c / VEC, ci = c - cv * VEC;
+  if (live)
     for (size_t p = rl; p < a.npix; p += 32) {
       const size_t e = p * a.C + c;
-      float g = val(a.g, e);
       const float y = val(a.y, e);
-      if (a.mask == 2) {
-        if (a.maskbits != nullptr) { if (!((a.maskbits[p * vpc + cv] >> ci) & 1u)) g = 0.f; }
-        else if (!(val(a.out, e) > 0.f)) g = 0.f;
-      } else if (a.mask == 1) {
-        if (!(fmaf(y, sc, sh) > 0.f)) g = 0.f;
-      }
+      const float g = masked_g(p, e, y);
       s1 += (double)g;
       s2 += (double)g * (((double)y - mu) * rs);
     }
-  }
   red[rl][cl][0] = s1; red[rl][cl][1] = s2;
   __syncthreads();
-  if (!live || rl != 0) return;
-  for (int k = 1; k < 32; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-  a.dbeta[c] += (float)s1;
-  a.dgamma[c] += (float)s2;
-  a.coef[2 * c] = (float)(s1 / (double)a.npix);
-  a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
+  s1 = 0.0; s2 = 0.0;
+  for (int k = 0; k < 32; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }   // every lane: the same fixed order
+  if (!live) return;
+  if (rl == 0) {
+    a.dbeta[c] += (float)s1;
+    a.dgamma[c] += (float)s2;
+    a.coef[2 * c] = (float)(s1 / (double)a.npix);
+    a.coef[2 * c + 1] = (float)(s2 / (double)a.npix);
+  }
+  const double c0 = s1 / (double)a.npix, c1 = s2 / (double)a.npix, A = (double)a.gamma[c] * rs;
+  for (size_t p = rl; p < a.npix; p += 32) {
+    const size_t e = p * a.C + c;
+    const float y = val(a.y, e);
+    const float g = masked_g(p, e, y);
+    if (a.res_grad != nullptr) put(a.res_grad, e, a.res_store ? g : g + val(a.res_grad, e));
+    put(a.dy, e, (float)(A * ((double)g - c0 - (((double)y - mu) * rs) * c1)));
+  }
 }
 hipError_t launch_bn_bwd_small(int dtype, const BnBwdArgs& a, hipStream_t st) {
   OCTSEG_NO_F16(dtype);

@@ -194,6 +194,9 @@ hipError_t launch_image_sum(int dtype, const void* in, void* out, int N, int HW,
 hipError_t launch_image_bcast(int dtype, const void* in, void* out, int N, int HW, int C, float scale, int accum, hipStream_t st);              // out [N][HW][C] (+)= scale * in [N][C]
 hipError_t launch_drop_elem(int dtype, const void* in, const float* keep, float mscale, void* out, size_t numel, hipStream_t st);                // out = in * keep * mscale
 hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H, int W, int C, int up, hipStream_t st);                         // NHWC, align_corners=True
+// ---- DeepLabV3 (deeplab.hip): dense dilated convs as plain 3x3 convs on a mosaic of the rate^2 sub-grids
+hipError_t launch_mosaic(int dtype, const void* src, void* dst, int N, int H, int W, int C, int r, int to_mosaic, int accum, hipStream_t st);      // fine [N][H][W][C] <-> mosaic [N][r (hs + 1) + 1][r (ws + 1) + 1][C]
+hipError_t launch_tensor_stats(int dtype, const void* y, size_t npix, int C, float* slab, int rows, hipStream_t st);                            // slab [rows][C][2] = (sum, sum of squares)
 // ---- PSPNet (deeplab.hip)
 hipError_t launch_bin_mean(int dtype, const void* in, void* out, int N, int H, int W, int C, int k, hipStream_t st);                              // AdaptiveAvgPool2d((k, k)): out [N][k][k][C]
 hipError_t launch_bin_mean_bwd(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int k, int accum, hipStream_t st);

@@ -248,7 +248,7 @@ struct Builder {
   // conv (+ optional BN whose statistics the epilogue emits).  Returns Value{raw output, bn}.
   Value conv(const std::string& name, const std::vector<ConvSrc>& srcs, int Cout, int R, int stride, int pad,
              const std::string& bn_name, bool bias, bool transposed = false, bool head = false,
-             bool stem = false, bool bn_lazy = true, int accum_into = -1) {
+             bool stem = false, bool bn_lazy = true, int accum_into = -1, bool defer_fin = false) {
     ConvLayer L;
     L.name = name; L.R = R; L.S = R; L.stride = stride; L.pad = pad;
     L.transposed = transposed; L.head = head; L.stem = stem; L.srcs = srcs; L.Cout = Cout;
@@ -277,8 +277,10 @@ struct Builder {
     if (!bn_name.empty()) {
       const int b = bn(bn_name, Cout, L.out, bn_lazy);
       P->convs[ci].bn = b;
-      Op f; f.kind = OP_BN_FIN; f.bn = b;
-      P->ops.push_back(f);
+      if (!defer_fin) {            // (deferred: the statistics come from another tensor, stats_fin() finishes the BatchNorm)
+        Op f; f.kind = OP_BN_FIN; f.bn = b;
+        P->ops.push_back(f);
+      }
       v.bn = b;
     }
     return v;
@@ -364,6 +366,26 @@ struct Builder {
     P->ops.push_back(op);
     return o;
   }
+  // ---- DeepLabV3 pieces: a dense dilated 3x3 conv as a plain conv on the mosaic of its rate^2 sub-grids (deeplab.hip)
+  int mosaic(int in, int r, bool to_mosaic, int H = 0, int W = 0) {
+    const TensorInfo& t = P->tensors[in];
+    int o;
+    if (to_mosaic) { const int hs = (t.H + r - 1) / r, ws = (t.W + r - 1) / r; o = tensor(t.N, r * (hs + 1) + 1, r * (ws + 1) + 1, t.C); }
+    else o = tensor(t.N, H, W, t.C);
+    Op op; op.kind = OP_MOSAIC; op.in = in; op.out = o; op.up = r; op.oc0 = to_mosaic ? 1 : 0;
+    P->ops.push_back(op);
+    return o;
+  }
+  // the BatchNorm `bn` (created by a conv with defer_fin) normalises tensor y, not the conv's own output: statistics from y, then finalize
+  void stats_fin(int bn, int y) {
+    const TensorInfo& t = P->tensors[y];
+    P->bns[bn].y = y;
+    P->bns[bn].count = (double)t.N * t.H * t.W;
+    Op s; s.kind = OP_STATS; s.bn = bn; s.in = y;
+    P->ops.push_back(s);
+    Op f; f.kind = OP_BN_FIN; f.bn = bn;
+    P->ops.push_back(f);
+  }
   // ---- PSPNet pieces (smp decoders/pspnet, restated in oracle/nets.py)
   int binpool(int in, int k) {            // nn.AdaptiveAvgPool2d((k, k))
     const TensorInfo& t = P->tensors[in];
@@ -412,7 +434,9 @@ Value mat(int t) { Value v; v.t = t; v.bn = -1; return v; }
 // dilate4: smp's make_dilated(output_stride=16) -- every conv of layer4 at stride 1 / dilation 2.  Built as the ordinary layer4 (stride 1)
 // on the parity re-arrangement of layer3's output (deeplab.hip header): no dilated conv kernel exists or is needed.
 // depth: smp encoder_depth (5, or 3 for PSPNet: layer3 / layer4 keep their parameters and buffers but no op).
-std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 = false, int depth = 5) {
+// dilate3: smp's make_dilated(8) on top -- layer3 at dilation 2 (one parity re-arrangement), layer4 at dilation 4 (= dilation 2 on layer3's
+// sub-grids: a second, nested re-arrangement); both are undone behind layer4.
+std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 = false, int depth = 5, bool dilate3 = false) {
   octseg_plan* P = b.P;
   const bool bottleneck = enc == "resnet50" || enc == "resnet101" || enc == "resnet152";
   int nblocks[4];
@@ -433,7 +457,7 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 =
   for (int li = 0; li < 4; ++li) {
     const int planes = planes_l[li];
     const int exp = bottleneck ? 4 : 1;
-    const bool dil = dilate4 && li == 3;
+    const bool dil = (dilate4 && li == 3) || (dilate3 && li >= 2);
     if (li + 2 > depth) {               // a stage behind the last feature the decoder reads: parameters only
       for (int bi = 0; bi < nblocks[li]; ++bi) {
         const int stride = (bi == 0 && li > 0) ? 2 : 1;
@@ -471,7 +495,7 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 =
       x = b.bn_act(last, res, -1, true);
       inplanes = planes * exp;
     }
-    if (dil) x = b.parity(x, false);
+    if (dil && li == 3) { x = b.parity(x, false); if (dilate3) x = b.parity(x, false); }
     feats.push_back(x);
   }
   return feats;  // f1 (S/2) .. f5 (S/32)
@@ -563,7 +587,8 @@ static void assign_lanes(octseg_plan* P) {
 
 static int build_plan(octseg_plan* P) {
   Builder b{P, dtype_size(P->dtype)};
-  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus", P->arch == "pspnet" ? 3 : 5);  // f[0]=f1 .. f[4]=f5
+  const bool dlv3 = P->arch == "deeplabv3";
+  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus" || dlv3, P->arch == "pspnet" ? 3 : 5, dlv3);  // f[0]=f1 .. f[4]=f5
   while (f.size() < 5) f.push_back(f.back());       // (PSPNet: three features; the slots of the others are never read)
   std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
   std::vector<int> ench;
@@ -640,6 +665,36 @@ static int build_plan(octseg_plan* P) {
       seg[i] = t;
     }
     x = mat(b.merge4(seg));
+  } else if (P->arch == "deeplabv3") {
+    // smp DeepLabV3 (reference sweep, configs/tune.yaml:9-18) with its defaults: output stride 8, dense ASPP (12, 24, 36), decoder_channels
+    // 256, 3x3 conv + BN + ReLU, head = 1x1 conv + UpsamplingBilinear2d(8).  Only the last feature is read.
+    head_k = 1;
+    P->head_up = 8;
+    P->dropout_p = 0.5f;
+    const int X = f[4];                       // stride 8
+    const TensorInfo tx = P->tensors[X];
+    const std::string A = "decoder.0";
+    std::vector<ConvSrc> cat;
+    cat.push_back({b.conv(A + ".convs.0.0", {{mat(X), 0}}, 256, 1, 1, 0, A + ".convs.0.1", false), 0});
+    const int rates[3] = {12, 24, 36};
+    for (int i = 0; i < 3; ++i) {             // ASPPConv: dense dilated 3x3 as a plain 3x3 on the mosaic of its sub-grids, BN, ReLU
+      const std::string pre = A + ".convs." + std::to_string(i + 1);
+      const int m = b.mosaic(X, rates[i], true);
+      const Value v = b.conv(pre + ".0", {{mat(m), 0}}, 256, 3, 1, 1, pre + ".1", false, false, false, false, true, -1, true);
+      const int yf = b.mosaic(v.t, rates[i], false, tx.H, tx.W);
+      b.stats_fin(v.bn, yf);
+      Value vf; vf.t = yf; vf.bn = v.bn;
+      cat.push_back({vf, 0});
+    }
+    {
+      const std::string pre = A + ".convs.4";
+      const int g = b.gap(X);
+      const Value v = b.conv(pre + ".1", {{mat(g), 0}}, 256, 1, 1, 0, pre + ".2", false);
+      cat.push_back({mat(b.bcast(b.bn_act(v, Value(), -1, true), tx.H, tx.W)), 0});
+    }
+    const Value pr = b.conv(A + ".project.0", cat, 256, 1, 1, 0, A + ".project.1", false);
+    const int pd = b.drope(b.bn_act(pr, Value(), -1, true));
+    x = b.conv("decoder.1", {{mat(pd), 0}}, 256, 3, 1, 1, "decoder.2", false);
   } else if (P->arch == "pspnet") {
     // smp PSPNet (reference sweep, configs/tune.yaml:9-18) with its defaults: encoder_depth 3 (the stride-8 feature), pyramid pooling to
     // 1 / 2 / 3 / 6 bins, 1x1 conv to 512 + BN + ReLU, Dropout2d(0.2), 3x3 head + UpsamplingBilinear2d(8)
@@ -702,12 +757,12 @@ static int build_plan(octseg_plan* P) {
     b.dw(hm, t2, 256, wp2, 256, 1);
     x = b.conv("decoder.block2.0.1", {{mat(t2), 0}}, 256, 1, 1, 0, "decoder.block2.1", false);
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | pspnet)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | deeplabv3 | pspnet)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet") assign_lanes(P);
+  if (P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -1142,8 +1197,8 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       case OP_DROPE: {
         const TensorInfo& t = P->tensors[op.out];
         if (E.train && P->dropout_keep == nullptr)
-          return fail(OCTSEG_BAD_ARG, "DeepLabV3+ training forward: no dropout keep mask set (octseg_plan_set_dropout: device float "
-                                      "[B][H/16][W/16][256] of 0 / 1, NHWC)");
+          return fail(OCTSEG_BAD_ARG, "DeepLabV3(+) training forward: no dropout keep mask set (octseg_plan_set_dropout: device float "
+                                      "[B][H/s][W/s][256] of 0 / 1, NHWC; s = 16, DeepLabV3: 8)");
         HIPCHK(launch_drop_elem(P->dtype, E.act(op.in), E.train ? P->dropout_keep : nullptr, 1.0f / (1.0f - P->dropout_p), E.act(op.out),
                                 (size_t)t.N * t.H * t.W * t.C, st));
         break;
@@ -1156,6 +1211,19 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       case OP_BINPOOL: {
         const TensorInfo& t = P->tensors[op.in];
         HIPCHK(launch_bin_mean(P->dtype, E.act(op.in), E.act(op.out), t.N, t.H, t.W, t.C, op.up, st));
+        break;
+      }
+      case OP_MOSAIC: {
+        const TensorInfo& tf = P->tensors[op.oc0 ? op.in : op.out];   // the fine tensor
+        HIPCHK(launch_mosaic(P->dtype, E.act(op.in), E.act(op.out), tf.N, tf.H, tf.W, tf.C, op.up, op.oc0, 0, st));
+        break;
+      }
+      case OP_STATS: {
+        if (E.train) {
+          const BNInfo& b = P->bns[op.bn];
+          const TensorInfo& t = P->tensors[op.in];
+          HIPCHK(launch_tensor_stats(P->dtype, E.act(op.in), (size_t)t.N * t.H * t.W, b.C, slab_l, b.rows, st));
+        }
         break;
       }
       case OP_RESIZE: {
@@ -1233,9 +1301,10 @@ static int bn_backward(Exec& E, int bn, const void* g, int mask, const void* out
   if (fused_fin) { a.fpart = (double*)(E.ws + P->bwd_part_off); a.fcnt = (unsigned*)(E.ws + P->bwd_cnt_off); }
   E.ginit[b.y] = 1;   // written (stored) by the apply pass below
   const double tbytes = (double)a.npix * b.C * dtype_size(P->dtype);   // class 3 = HBM-bound sweeps: "flops" carries algorithmic bytes
-  if (a.npix <= (size_t)BN_SMALL_COUNT) {   // small tensors: one launch, double accumulation (elementwise.hip)
-    ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 3 : 2), E.st, b.name + ".bwd_reduce");
+  if (a.npix <= (size_t)BN_SMALL_COUNT) {   // small tensors: reduce, finalize and apply in one launch, in double (elementwise.hip)
+    ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 5 : 4), E.st, b.name + ".bwd_small");
     HIPCHK(launch_bn_bwd_small(P->dtype, a, E.st));
+    return OCTSEG_OK;
   } else {
     {
       ProfScope ps(3, tbytes * ((mask == 2 && !maskbits) ? 3 : 2), E.st, b.name + ".bwd_reduce");
@@ -1513,6 +1582,13 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         const TensorInfo& to = P->tensors[op.out];
         HIPCHK(launch_bilinear_resize_adjoint(P->dtype, E.grad(op.out), E.grad(op.in), ti.N, ti.H, ti.W, to.H, to.W, ti.C, E.st));
         E.ginit[op.in] = 1;
+        break;
+      }
+      case OP_STATS: break;
+      case OP_MOSAIC: {     // the inverse re-arrangement of the gradient (gutters of a mosaic gradient are zero)
+        const TensorInfo& tf = P->tensors[op.oc0 ? op.in : op.out];
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_mosaic(P->dtype, E.grad(op.out), E.grad(op.in), tf.N, tf.H, tf.W, tf.C, op.up, op.oc0 ? 0 : 1, op.oc0 ? acc : 0, E.st));
         break;
       }
       case OP_BINPOOL: {

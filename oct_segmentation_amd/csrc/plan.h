@@ -85,7 +85,10 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               OP_BINPOOL,    // out [N][k][k][C] = AdaptiveAvgPool2d((k, k)) of in, k = up
               OP_RESIZE,     // out = bilinear resize of in to out's size (align_corners=True)
               OP_RELU,       // out = relu(in) of a plain tensor (biased conv without BatchNorm)
-              OP_DROP2D };   // out = in * Dropout2d keep pattern [N][C] / (1 - p)
+              OP_DROP2D,     // out = in * Dropout2d keep pattern [N][C] / (1 - p)
+              // DeepLabV3 (deeplab.hip)
+              OP_MOSAIC,     // out = mosaic of the rate^2 sub-grids of in (oc0 = 1), or in's mosaic gathered back (oc0 = 0); rate = up
+              OP_STATS };    // BatchNorm partial sums of tensor `in` for BN `bn` (its producer is not a conv epilogue)
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV

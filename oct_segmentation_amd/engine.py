@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3')
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
@@ -165,7 +165,8 @@ class SegNet(nn.Module):
                      'encoder_output_stride': 16, 'decoder_atrous_rates': (12, 24, 36),
                      # smp.PSPNet's own keywords, at their defaults (encoder_depth, upsampling: see _ARCH_DEFAULTS)
                      'psp_out_channels': 512, 'psp_use_batchnorm': True, 'psp_dropout': 0.2}
-    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8}}
+    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8},
+                      'deeplabv3': {'decoder_channels': 256, 'upsampling': 8}}
 
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,
                  device='cuda', compute_dtype=torch.bfloat16, seed=None, **kwargs):
@@ -396,14 +397,15 @@ class SegNet(nn.Module):
         return x.contiguous()
 
     def _has_dropout(self):
-        return self.arch in ('fpn', 'deeplabv3plus', 'pspnet')
+        return self.arch in ('fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3')
 
     def _keep_shape(self, B, H, W):
         if self.arch == 'fpn':
             return (B, _FPN_SEG_CHANNELS), 1.0 - _FPN_DROPOUT
         if self.arch == 'pspnet':
             return (B, _PSP_CHANNELS), 1.0 - _PSP_DROPOUT
-        return (B, H // 16, W // 16, _DLV3P_CHANNELS), 1.0 - _DLV3P_DROPOUT
+        s = 8 if self.arch == 'deeplabv3' else 16          # DeepLabV3: output stride 8
+        return (B, H // s, W // s, _DLV3P_CHANNELS), 1.0 - _DLV3P_DROPOUT
 
     def _draw_keep(self, B, H, W, device):
         """The dropout keep pattern of one training forward, in the layout octseg_plan_set_dropout takes."""
@@ -412,7 +414,7 @@ class SegNet(nn.Module):
         if keep is None:
             return torch.bernoulli(torch.full(shape, pkeep, device=device))
         keep = keep.to(device, torch.float32)
-        if self.arch == 'deeplabv3plus' and keep.dim() == 4 and tuple(keep.shape) == (shape[0], shape[3], shape[1], shape[2]):
+        if self.arch in ('deeplabv3plus', 'deeplabv3') and keep.dim() == 4 and tuple(keep.shape) == (shape[0], shape[3], shape[1], shape[2]):
             keep = keep.permute(0, 2, 3, 1)      # torch's NCHW mask -> the engine's NHWC
         keep = keep.contiguous()
         if tuple(keep.shape) != shape:

@@ -403,21 +403,42 @@ class ASPPPooling(nn.Sequential):
         return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
 
 
-class ASPP(nn.Module):
-    """smp decoders/deeplabv3/decoder.py ASPP(separable=True): 1x1, three separable dilated 3x3, image pooling; concat; 1x1 project +
-    BN + ReLU + Dropout(0.5) (element-wise)."""
+class ASPPConv(nn.Sequential):
+    def __init__(self, cin, cout, dilation):
+        super().__init__(nn.Conv2d(cin, cout, 3, padding=dilation, dilation=dilation, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
 
-    def __init__(self, cin, cout, atrous_rates):
+
+class ASPP(nn.Module):
+    """smp decoders/deeplabv3/decoder.py ASPP: 1x1, three dilated 3x3 (separable for DeepLabV3+, dense for DeepLabV3), image pooling;
+    concat; 1x1 project + BN + ReLU + Dropout(0.5) (element-wise)."""
+
+    def __init__(self, cin, cout, atrous_rates, separable=True):
         super().__init__()
         mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())]
         for r in atrous_rates:
-            mods.append(ASPPSeparableConv(cin, cout, r))
+            mods.append(ASPPSeparableConv(cin, cout, r) if separable else ASPPConv(cin, cout, r))
         mods.append(ASPPPooling(cin, cout))
         self.convs = nn.ModuleList(mods)
         self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(), InjectableDropout(0.5))
 
     def forward(self, x):
         return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+
+
+class DeepLabV3Decoder(nn.Sequential):
+    """smp DeepLabV3Decoder: dense ASPP on the last feature (output stride 8), 3x3 conv + BN + ReLU."""
+
+    def __init__(self, cin, out_channels=256, atrous_rates=(12, 24, 36)):
+        super().__init__(ASPP(cin, out_channels, atrous_rates, separable=False),
+                         nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.out_channels = out_channels
+
+    @property
+    def dropout(self):
+        return self[0].project[3]
+
+    def forward(self, *features):
+        return super().forward(features[-1])
 
 
 class DeepLabV3PlusDecoder(nn.Module):
@@ -540,6 +561,11 @@ class SegmentationModel(nn.Module):
             # smp PSPNet defaults: encoder_depth=3, psp_out_channels=512, psp_use_batchnorm=True, psp_dropout=0.2, upsampling=8, 3x3 head
             self.decoder = PSPDecoder(ch)
             self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 3, upsampling=8)
+        elif arch == 'deeplabv3':
+            # smp DeepLabV3 defaults: output stride 8 (layer3 dilation 2, layer4 dilation 4), decoder_channels=256, upsampling=8
+            self.encoder.make_dilated(8)
+            self.decoder = DeepLabV3Decoder(ch[-1])
+            self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 1, upsampling=8)
         elif arch == 'deeplabv3plus':
             # smp DeepLabV3Plus defaults: encoder_output_stride=16, decoder_channels=256, decoder_atrous_rates=(12, 24, 36), upsampling=4
             self.encoder.make_dilated(16)
@@ -559,7 +585,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):

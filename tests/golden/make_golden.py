@@ -36,6 +36,7 @@ CASES = {
     'fpn_resnet18_64x96': ('fpn', 'resnet18', 2, 2, (64, 96), 140),
     'deeplabv3plus_resnet18_64x96': ('deeplabv3plus', 'resnet18', 2, 4, (64, 96), 141),
     'pspnet_resnet18_96x64': ('pspnet', 'resnet18', 2, 3, (96, 64), 142),
+    'deeplabv3_resnet18_64x96': ('deeplabv3', 'resnet18', 1, 4, (64, 96), 143),
 }
 # Lightning-DDP semantics (reference train.py:122-133 with devices > 1): the global batch is split
 # into `world` contiguous shards, every rank runs forward + Dice + backward on ITS shard with local BatchNorm statistics
@@ -60,7 +61,7 @@ def case_batch(B, classes, S, seed, arch=None):
         img, mask = img[:, :, :H, :W].contiguous(), mask[:, :, :H, :W].contiguous()
     else:
         img, mask = make_batch(B, classes, S, seed=seed, empty_last=(classes > 1))
-    if arch in ('deeplabv3plus', 'pspnet'):
+    if arch in ('deeplabv3plus', 'pspnet', 'deeplabv3'):
         img = (img * (0.35 + 0.65 * torch.arange(B).view(B, 1, 1, 1) / max(1, B - 1))).round().contiguous()
     return img, mask
 
@@ -74,8 +75,9 @@ def case_keep(arch, B, S, seed):
         return (torch.rand(B, 128, generator=g) < 0.8).float()
     if arch == 'pspnet':
         return (torch.rand(B, 512, generator=g) < 0.8).float()
-    if arch == 'deeplabv3plus':
-        return (torch.rand(B, 256, H // 16, W // 16, generator=g) < 0.5).float()
+    if arch in ('deeplabv3plus', 'deeplabv3'):
+        s_ = 16 if arch == 'deeplabv3plus' else 8
+        return (torch.rand(B, 256, H // s_, W // s_, generator=g) < 0.5).float()
     return None
 
 
@@ -104,7 +106,7 @@ def build(arch, enc, classes, seed, kinkfree=True):
             for mod in m.modules():
                 if isinstance(mod, torch.nn.BatchNorm2d):
                     mod.bias.copy_(8.0 * ((torch.rand(mod.bias.shape, generator=g) < 0.7).float() * 2 - 1))
-            if arch in ('fpn', 'deeplabv3plus', 'pspnet'):
+            if arch in ('fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3'):
                 # their heads sit straight behind normalisation layers with +-8 biases (summed four times in FPN): keep |logits| of order 1,
                 # a saturated sigmoid has no gradient to compare
                 for mod in m.modules():

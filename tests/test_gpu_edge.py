@@ -373,7 +373,7 @@ def test_captured_training_step_equals_eager_bit_for_bit(cuda, arch, enc, dtype)
     assert not torch.equal(eager[1][3], eager[2][3]) and not torch.equal(eager[1][3], eager[3][3])
 
 
-@pytest.mark.parametrize('arch', ['FPN', 'DeepLabV3Plus', 'PSPNet'])
+@pytest.mark.parametrize('arch', ['FPN', 'DeepLabV3Plus', 'PSPNet', 'DeepLabV3'])
 def test_sweep_architectures_through_the_model_class(cuda, tmp_path, arch):
     """The reference's sweep passes `architecture` straight to smp.create_model (configs/tune.yaml:9-18, model.py:38-44): the mirror class
     trains, validates, checkpoints and predicts with the two sweep architectures of round 3 exactly as with the BASELINE trio."""

@@ -1,4 +1,4 @@
-"""Seeded fuzz over the sweep architectures added in round 3 (FPN, DeepLabV3+, PSPNet): random encoder x batch x classes x
+"""Seeded fuzz over the sweep architectures added in round 3 (FPN, DeepLabV3+, PSPNet, DeepLabV3): random encoder x batch x classes x
 non-square frame, kink-free normalisation biases (so that fp32 implementations agree on every ReLU mask), the oracle's dropout pattern
 injected.  Bounds of the per-architecture tests: logits 1e-4 of their scale (2e-4 behind the 50+-layer encoders), Dice 1e-5, counts exact,
 gradient cosine 1 - 1e-6, every parameter within 2e-3 of its largest element or re-judged against float64 (test_gpu_deeplab.judge_gradients).
@@ -10,26 +10,28 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _cases(n=15, seed=2024, keep=(0, 1, 2, 3, 5, 7, 10, 12, 13)):
+def _cases(n=18, seed=2024, keep=(0, 1, 2, 3, 5, 7, 10, 12, 13, 15, 16, 17)):
     rng = np.random.default_rng(seed)
     out = []
     for k in range(n):
-        arch = ['fpn', 'deeplabv3plus'][k % 2] if k < 10 else 'pspnet'    # (PSPNet cases appended: the first ten keep their draws)
+        arch = ['fpn', 'deeplabv3plus'][k % 2] if k < 10 else ('pspnet' if k < 15 else 'deeplabv3')   # (appended: earlier draws unchanged)
         enc = ['resnet18', 'resnet34', 'resnet50'][rng.integers(3)]      # (resnet101 cost 35 s per float64 re-judge; its blocks are resnet50's)
         B = int(rng.integers(2, 5)) if arch == 'fpn' else int(rng.integers(3, 5))
         classes = int(rng.integers(1, 4))
         H, W = (int(32 * rng.integers(2, 5)) for _ in range(2))
+        if arch == 'deeplabv3':      # output stride 8 with layer4 on 16 nested sub-grids: frames below 96 px leave 2x2-pixel maps
+            H, W = max(H, 96), max(W, 96)
         out.append((k, arch, enc, B, classes, H, W))
-    return [c for c in out if c[0] in keep]      # three per architecture (the GPU suite's time budget); the draws of all 15 stay as they were
+    return [c for c in out if c[0] in keep]      # three per architecture (the GPU suite's time budget); the draws of all 18 stay as they were
 
 
 @pytest.mark.parametrize('case', _cases(), ids=lambda c: f'{c[0]}-{c[1]}-{c[2]}-B{c[3]}-C{c[4]}-{c[5]}x{c[6]}')
 def test_fuzz_f4_fp32(cuda, case):
     from oracle import get_stats
     from test_gpu_net import _grad_report
-    import test_gpu_deeplab, test_gpu_fpn, test_gpu_pspnet
+    import test_gpu_deeplab, test_gpu_deeplabv3, test_gpu_fpn, test_gpu_pspnet
     k, arch, enc, B, classes, H, W = case
-    pair = {'fpn': test_gpu_fpn._pair, 'deeplabv3plus': test_gpu_deeplab._pair, 'pspnet': test_gpu_pspnet._pair}[arch]
+    pair = {'fpn': test_gpu_fpn._pair, 'deeplabv3plus': test_gpu_deeplab._pair, 'pspnet': test_gpu_pspnet._pair, 'deeplabv3': test_gpu_deeplabv3._pair}[arch]
     ref, net, img, mask, z, loss_ref, logits, loss, stats = pair(cuda, enc, classes, B, H, W, seed=100 + k, kinkfree=True)
     scale = z.abs().max().item()
     err = (logits - z).abs().max().item()

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 @pytest.mark.parametrize('name', ['unet_resnet18', 'unetplusplus_resnet18', 'linknet_resnet18', 'unet_resnet50', 'unetplusplus_resnet50',
                                   'linknet_resnet50', 'unet_resnet18_96x64', 'c1_unet_resnet18_256', 'unetplusplus_resnet101',
-                                  'fpn_resnet18_64x96', 'deeplabv3plus_resnet18_64x96', 'pspnet_resnet18_96x64'])
+                                  'fpn_resnet18_64x96', 'deeplabv3plus_resnet18_64x96', 'pspnet_resnet18_96x64', 'deeplabv3_resnet18_64x96'])
 def test_engine_reproduces_golden_vectors(cuda, name):
     from golden.make_golden import CASES, build, case_batch, case_keep, summarize_logits
     from oct_segmentation_amd.engine import SegNet

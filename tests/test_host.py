@@ -78,7 +78,7 @@ def test_plan_argument_validation():
     assert rc == -1 and b'divisible by 32' in lib.octseg_last_error()   # smp check_input_shape text
     rc, _ = _plan('manet', 'resnet18', 1, 1, 64, 64)       # (an smp architecture outside the built set)
     assert rc == -3
-    for arch in ('fpn', 'deeplabv3plus', 'DeepLabV3Plus', 'PSPNet'):  # sweep architectures built since round 3 (case-insensitive like smp)
+    for arch in ('fpn', 'deeplabv3plus', 'DeepLabV3Plus', 'PSPNet', 'DeepLabV3'):  # sweep architectures built since round 3 (case-insensitive like smp)
         rc, pf = _plan(arch, 'resnet18', 1, 1, 64, 64)
         assert rc == 0
         lib.octseg_plan_destroy(pf)
@@ -220,4 +220,4 @@ def test_planner_and_executors_clean_under_asan_ubsan():
     r = subprocess.run([os.path.join(csrc, 'build', 'asan', 'plan_dryrun')], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-6000:]
-    assert '540 plans built' in r.stdout and '0 errors' in r.stdout, r.stdout
+    assert '630 plans built' in r.stdout and '0 errors' in r.stdout, r.stdout

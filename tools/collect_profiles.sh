@@ -15,7 +15,7 @@ OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_alone.csv python3 bench.py --steps 
 python3 tools/group_layers.py gpurun_out/${tag}_layers_alone.csv 2 > gpurun_out/${tag}_layer_groups.txt
 python3 bench.py --workload ensemble_704_fp16 --steps 30 > gpurun_out/${tag}_ensemble_b1.json 2> /dev/null
 python3 bench.py --workload ensemble_704_fp16 --steps 20 --batch 8 > gpurun_out/${tag}_ensemble_b8.json 2> /dev/null
-for w in linknet_r50_704 unet_r50_704 fpn_r50_704 deeplabv3plus_r50_704 pspnet_r50_704; do
+for w in linknet_r50_704 unet_r50_704 fpn_r50_704 deeplabv3plus_r50_704 pspnet_r50_704 deeplabv3_r50_704; do
   OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_$w.csv python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> /dev/null
   python3 tools/group_layers.py gpurun_out/${tag}_layers_$w.csv 2 > gpurun_out/${tag}_layer_groups_$w.txt; rm -f gpurun_out/${tag}_layers_$w.csv
 done

@@ -40,8 +40,8 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
   void* wsp = carve(ws);
   float* image = (float*)carve(px * 3 * 4); float* logits = (float*)carve(px * d.classes * 4); float* target = (float*)carve(px * d.classes * 4);
   float* loss = (float*)carve(4); long long* stats = (long long*)carve((size_t)d.batch * d.classes * 4 * 8);
-  const bool dl = !strcmp(d.arch, "deeplabv3plus");   // fpn: Dropout2d pattern [B][128]; deeplabv3plus: element-wise [B][H/16][W/16][256]
-  float* keep = (float*)carve(dl ? (size_t)d.batch * (d.height / 16) * (d.width / 16) * 256 * 4 : (size_t)d.batch * 512 * 4);   // (pspnet: [B][512])
+  const int dls = !strcmp(d.arch, "deeplabv3plus") ? 16 : !strcmp(d.arch, "deeplabv3") ? 8 : 0;   // element-wise [B][H/s][W/s][256]; fpn [B][128], pspnet [B][512]
+  float* keep = (float*)carve(dls ? (size_t)d.batch * (d.height / dls) * (d.width / dls) * 256 * 4 : (size_t)d.batch * 512 * 4);
   octseg_plan_set_dropout(p, keep);                 // (ignored by the other architectures)
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   void* st = (void*)(uintptr_t)0x4000; void* comm = (void*)(uintptr_t)0x4100;
@@ -82,7 +82,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 }  // namespace
 
 int main() {
-  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet"};
+  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3"};
   const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
