@@ -136,10 +136,10 @@ def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     assert judge_gradients(ref, grads, img, mask) <= 1
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 704, 704), (3, 352, 416)])
+@pytest.mark.parametrize('B,H,W', [(2, 704, 704)])
 def test_deeplab_dilation_rates_in_range_fp32(cuda, B, H, W):
     """The small frames above leave the ASPP's rates (12, 24, 36) outside their 4x4 .. 8x8 maps: only the centre taps of the dilated
-    depthwise convs ever touch data there.  At the BASELINE frame size the stride-16 map is 44 x 44 (and 22 x 26 for the second case) and
+    depthwise convs ever touch data there.  At the BASELINE frame size the stride-16 map is 44 x 44 and
     every tap of every rate lands inside: the same fp32 bounds, against the same oracle, kink-free."""
     from test_gpu_net import _grad_report
     ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, 'resnet18', 1, B, H, W, seed=7, kinkfree=True)
