@@ -118,7 +118,7 @@ def judge_gradients(ref, grads, img, mask, tag=''):
     return len(loose)
 
 
-@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet50', 1, 4, 96, 64)])
+@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet34', 1, 4, 96, 64)])   # (resnet50: fuzz case k = 7, 24 s of float64)
 def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     """BatchNorm biases at +-8 (no pre-activation near the ReLU kink): every parameter gradient -- depthwise kernels, pointwise convs, the
     pooled branch, the dilated layer4 through the parity re-arrangement, the whole encoder -- within 2e-3 of its largest element.
