@@ -225,6 +225,19 @@ class SegNet(nn.Module):
         self.register_buffer('num_batches_tracked', torch.zeros((), dtype=torch.long))
         self._grad_arena = torch.zeros(self.param_numel, dtype=torch.float32, device=self.device)
         self._by_name = {p['name']: p for p in self.param_table}
+        # element ranges of the arena that an optimizer may touch.  PSPNet (smp encoder_depth 3) keeps encoder.layer3 / layer4 in its
+        # state_dict without ever running them: torch optimizers skip parameters whose gradient is None, so weight decay must not
+        # reach them here either -- the fused optimizer steps over the live ranges only
+        dead = ('encoder.layer3.', 'encoder.layer4.') if a == 'pspnet' else ()
+        self._dead_prefixes = dead
+        self.live_ranges, lo = [], 0
+        for p in sorted(self.param_table, key=lambda q: q['offset']):
+            if p['name'].startswith(dead) if dead else False:
+                if p['offset'] > lo:
+                    self.live_ranges.append((lo, p['offset']))
+                lo = p['offset'] + (p['numel'] + 3) // 4 * 4
+        if lo < self.param_numel:
+            self.live_ranges.append((lo, self.param_numel))
         self.initialize(seed)
         self.load_encoder_weights(encoder_weights)
 
@@ -343,7 +356,8 @@ class SegNet(nn.Module):
                 base = prefix + b['name']
                 sd[base + '.running_mean'] = self.bn_buffers[b['mean_offset']:b['mean_offset'] + b['C']].clone()
                 sd[base + '.running_var'] = self.bn_buffers[b['var_offset']:b['var_offset'] + b['C']].clone()
-                sd[base + '.num_batches_tracked'] = self.num_batches_tracked.clone()
+                dead_bn = bool(self._dead_prefixes) and b['name'].startswith(self._dead_prefixes)     # never ran: torch's counter stays 0
+                sd[base + '.num_batches_tracked'] = torch.zeros_like(self.num_batches_tracked) if dead_bn else self.num_batches_tracked.clone()
         return sd
 
     def load_state_dict(self, state_dict, strict=True):
@@ -367,7 +381,7 @@ class SegNet(nn.Module):
                     if k in state_dict:
                         self.bn_buffers[off:off + b['C']] = state_dict[k].to(self.device, torch.float32)
                 k = f"{b['name']}.num_batches_tracked"
-                if k in state_dict:
+                if k in state_dict and not (self._dead_prefixes and b['name'].startswith(self._dead_prefixes)):
                     self.num_batches_tracked.copy_(state_dict[k])
         self.params_changed()   # the views write through arena.data, which torch's version counter does not see
         return nn.modules.module._IncompatibleKeys(missing, unexpected)

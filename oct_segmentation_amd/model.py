@@ -54,9 +54,10 @@ class FusedOptimizer:
             raise RuntimeError('optimizer.step() called before any backward')
         self.step_count += 1
         self.lr = float(self.param_groups[0]['lr'])
-        L.check(L.lib().octseg_optim_step(self.kind, L.ptr(self.net.arena.data), L.ptr(g), L.ptr(self.m), L.ptr(self.v),
-                                          self.net.param_numel, self.lr, self.weight_decay, self.step_count,
-                                          float(grad_scale), L.stream_ptr()))
+        for lo, hi in getattr(self.net, 'live_ranges', [(0, self.net.param_numel)]):     # (one range for every net but PSPNet: engine.py)
+            L.check(L.lib().octseg_optim_step(self.kind, L.ptr(self.net.arena.data[lo:hi]), L.ptr(g[lo:hi]),
+                                              L.ptr(None if self.m is None else self.m[lo:hi]), L.ptr(None if self.v is None else self.v[lo:hi]),
+                                              hi - lo, self.lr, self.weight_decay, self.step_count, float(grad_scale), L.stream_ptr()))
         self.net.params_changed()
 
     def state_dict(self):

@@ -146,3 +146,34 @@ def test_pspnet_eval_bf16_and_704(cuda):
     half.load_state_dict(net2.state_dict())
     assert torch.isfinite(half(i2.to(cuda))).all()
     assert np.isfinite(loss_b.item())
+
+
+def test_pspnet_dead_stages_are_left_alone_by_the_optimizer(cuda):
+    """torch optimizers skip parameters without a gradient (encoder.layer3 / layer4 of smp's encoder_depth=3 PSPNet), so their weight decay
+    never touches them; the fused optimizer steps over the live ranges of the arena only.  Live parameters follow torch.optim.Adam."""
+    from oct_segmentation_amd.engine import SegNet
+    from oct_segmentation_amd.model import FusedOptimizer
+    from oracle import DiceLoss
+    ref = _oracle_psp('resnet18', 1, seed=21, kinkfree=False).train()
+    net = SegNet('pspnet', 'resnet18', classes=1, device=cuda, compute_dtype=torch.float32).train()
+    net.load_state_dict(ref.state_dict())
+    assert len(net.live_ranges) == 2
+    img, mask = make_batch(3, 1, 64, seed=8)
+    keep = (torch.rand(3, 512, generator=torch.Generator().manual_seed(1)) < 0.8).float()
+    ref.decoder.dropout.mask = keep
+    net.dropout_keep = keep
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    opt = FusedOptimizer(net, 'Adam', 1e-3, 1e-2)
+    before = {k: v.clone() for k, v in ref.state_dict().items()}
+    DiceLoss()(ref(img), mask).backward()
+    opt_ref.step()
+    net.train_step_raw(img.to(cuda), mask.to(cuda))
+    opt.step()
+    sd, rd = net.state_dict(), ref.state_dict()
+    for k, v in rd.items():
+        if k.startswith('encoder.layer3.') or k.startswith('encoder.layer4.'):
+            assert torch.equal(sd[k].cpu(), before[k]), k                    # untouched, as in torch
+        elif v.dtype.is_floating_point and 'running' not in k:
+            d = (sd[k].cpu() - v).abs()
+            # Adam's first step is lr * g / (|g| + eps): an element whose gradient is rounding noise may move by lr in either direction
+            assert d.max().item() <= 2.2e-3 and d.mean().item() <= 5e-5, (k, d.max().item(), d.mean().item())
