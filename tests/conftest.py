@@ -8,8 +8,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cores():
+    """CPU threads this process may really use (bench.py host_cores): the affinity mask, cut to the cgroup quota; a one-GPU job on the
+    GPU boxes sees every core of the host but is scheduled on a 16-core share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()
+            if q != 'max':
+                return max(1, min(n, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return 16 if n > 32 else n
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle (torch / oneDNN) with one thread per VISIBLE core oversubscribes the box's share by an order of magnitude
+    import torch
+    torch.set_num_threads(_usable_cores())
 
 
 @pytest.fixture(scope='session')

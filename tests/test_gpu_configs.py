@@ -142,7 +142,7 @@ def test_c5_ensemble_704_graph_replay(cuda, tmp_path):
     _ = rng
 
 
-BF16_PARITY = [('linknet', 'resnet50', 2, 2, 256), ('unetplusplus', 'resnet101', 1, 2, 256),      # (U-Net++/resnet50 until round 3: 13 s; resnet101 holds the same blocks)
+BF16_PARITY = [('unetplusplus', 'resnet50', 1, 2, 256), ('linknet', 'resnet50', 2, 2, 256), ('unetplusplus', 'resnet101', 1, 2, 256),
                # 9 x 64 x 64 = 288 M tiles in layer1: the persistent 1x1 GEMM (gemm1x1.hip) walks several tiles per workgroup with
                # its BatchNorm partial sums carried across them (conv3: two N tiles on 256 workgroup rows)
                ('unet', 'resnet50', 1, 9, 256)]

