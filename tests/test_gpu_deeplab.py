@@ -82,7 +82,7 @@ def test_deeplab_train_step_parity_fp32(cuda, enc, classes, B, H, W):
             assert d <= 1e-4 * max(1.0, rd[k].abs().max().item()), (k, d)
 
 
-def judge_gradients(ref, grads, img, mask, tag=''):
+def judge_gradients(ref, grads, img, mask, tag='', normalize=True):
     """Per parameter: within 2e-3 of its largest element; a parameter that misses it is re-judged against a float64 run of the oracle (the
     fuzz test's criterion: at most 4x as far from the exact gradient as torch's own fp32 is).  What needs it: the 1x1 conv of DeepLabV3+'s
     pooled ASPP branch sits in front of a BatchNorm over B values per channel, whose input gradient g - mean(g) - x_hat mean(g x_hat)
@@ -100,10 +100,11 @@ def judge_gradients(ref, grads, img, mask, tag=''):
         return 0
     ref64 = copy.deepcopy(ref).double()
     ref64.zero_grad()
-    if ref.decoder.dropout.mask is not None:
-        ref64.decoder.dropout.mask = ref.decoder.dropout.mask.double()
+    drop = getattr(ref.decoder, 'dropout', None)
+    if drop is not None and getattr(drop, 'mask', None) is not None:
+        ref64.decoder.dropout.mask = drop.mask.double()
     mean = torch.tensor(MEAN).view(1, 3, 1, 1).double(); std = torch.tensor(STD).view(1, 3, 1, 1).double()
-    DiceLoss()(ref64((img.double() - mean) / std), mask.double()).backward()
+    DiceLoss()(ref64((img.double() - mean) / std if normalize else img.double()), mask.double()).backward()
     p64, p32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
     ratios = []
     for n in loose:

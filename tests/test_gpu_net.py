@@ -337,10 +337,15 @@ def test_fused_optimizer_matches_torch(cuda, opt):
     assert err < 1e-5
 
 
-@pytest.mark.parametrize('arch,enc,S,B', [('unetplusplus', 'resnet34', 256, 2), ('unet', 'resnet50', 224, 3), ('linknet', 'resnet34', 320, 2)])
+@pytest.mark.parametrize('arch,enc,S,B', [('unetplusplus', 'resnet34', 256, 2), ('unet', 'resnet50', 224, 3), ('linknet', 'resnet34', 320, 2),
+                                          # the BASELINE frame size itself, one frame (fp32 against the oracle, not a property test)
+                                          ('unetplusplus', 'resnet34', 704, 1), ('linknet', 'resnet50', 704, 1), ('unet', 'resnet50', 704, 1),
+                                          ('unetplusplus', 'resnet101', 704, 1)])      # (the benchmark's own network)
 def test_parity_at_larger_frames_fp32(cuda, arch, enc, S, B):
     """The same train-step parity on frames large enough for multi-chunk 16x16 tiles, ragged borders (224 = 14 x 16,
-    320 / 32 = 10) and every main loop of the conv kernel; kink-free BN biases so that gradients are comparable."""
+    320 / 32 = 10) and every main loop of the conv kernel; kink-free BN biases so that gradients are comparable.  The 704 x 704 cases
+    are the three BASELINE architectures at the BASELINE frame size, where the persistent 3x3 kernel, the thin full-resolution kernels and
+    the stem kernel take the layers they take in the benchmark."""
     from oracle import create_model, DiceLoss
     from oracle.nets import randomize_bn
     from oct_segmentation_amd.engine import SegNet
@@ -368,4 +373,9 @@ def test_parity_at_larger_frames_fp32(cuda, arch, enc, S, B):
     print(f'{arch}/{enc} {S}x{S}: logits max|d| {err:.2e} (scale {scale:.1f}), grad cosine {cos:.9f}, worst {worst:.2e} ({name})')
     assert err <= 2e-4 * max(1.0, scale)
     assert abs(loss.item() - loss_ref.item()) <= 1e-5
-    assert cos >= 0.999999 and worst < 2e-3
+    assert cos >= 0.999999
+    if S < 704:
+        assert worst < 2e-3
+    else:   # half a million pixels per frame: fp32 sums of that length (biases, split-K weight gradients) are judged against float64
+        from test_gpu_deeplab import judge_gradients
+        judge_gradients(ref, net.named_grads(), img, mask, tag=f'{arch}/{enc} {S}: ', normalize=False)
