@@ -145,7 +145,9 @@ def test_c5_ensemble_704_graph_replay(cuda, tmp_path):
 BF16_PARITY = [('unetplusplus', 'resnet50', 1, 2, 256), ('linknet', 'resnet50', 2, 2, 256), ('unetplusplus', 'resnet101', 1, 2, 256),
                # 9 x 64 x 64 = 288 M tiles in layer1: the persistent 1x1 GEMM (gemm1x1.hip) walks several tiles per workgroup with
                # its BatchNorm partial sums carried across them (conv3: two N tiles on 256 workgroup rows)
-               ('unet', 'resnet50', 1, 9, 256)]
+               ('unet', 'resnet50', 1, 9, 256),
+               # the benchmark's network at the benchmark's frame size (two frames): bf16 engine against the fp32 oracle
+               ('unetplusplus', 'resnet101', 1, 2, 704)]
 
 
 @pytest.mark.parametrize('cfg', BF16_PARITY, ids=['-'.join(map(str, c)) for c in BF16_PARITY])
