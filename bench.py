@@ -223,11 +223,15 @@ def bench_ensemble(args):
     rows = torch.from_numpy(cv2_nearest_index(S, OUT)).to(dev)
     lib = L.lib()
 
+    side_by_side = not args.no_graph and not args.serial_nets
+
     def step():
-        for net, classes in nets:
+        # replayed graphs of the three nets are started together, each on its plan's own stream, and joined in order (SegNet.forward_async)
+        handles = [net.forward_async(x, normalize=False) if (side_by_side and net.use_graph) else None for net, _ in nets]
+        for (net, classes), h in zip(nets, handles):
             if os.environ.get('OCTSEG_BENCH_TRACE'):
                 print(f'[bench] {net.arch}/{net.encoder_name}', file=sys.stderr, flush=True)
-            z = net(x, normalize=False)
+            z = net.forward_join(h) if h is not None else net(x, normalize=False)
             for cl in classes:
                 ch = MODELS_META[cl]['index'] if z.shape[1] > 1 else 0
                 L.check(lib.octseg_mask_assemble(L.ptr(z), B, z.shape[1], S, S, int(ch), L.ptr(stack), OUT, OUT, 4, CLASS_IDS[cl] - 1,
@@ -289,6 +293,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='unetpp_r101_704', choices=sorted(WORKLOADS) + ['ensemble_704_fp16'])
     ap.add_argument('--no-graph', action='store_true', help='ensemble workload: eager launches instead of replayed hipGraphs')
+    ap.add_argument('--serial-nets', action='store_true', help='ensemble workload: one net after the other instead of the three replays side by side')
     ap.add_argument('--batch', type=int, default=16, help='frames per GPU (weak scaling) / frames in the global batch (strong scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: --batch frames per GPU whatever N; strong: the global batch stays --batch, every GPU gets batch/N frames')

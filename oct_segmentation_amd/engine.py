@@ -480,7 +480,7 @@ class SegNet(nn.Module):
         self._buffer_epoch += 1
         return io['loss'].clone(), io['logits'].clone(), io['stats'].clone()
 
-    def _run_forward(self, x, normalize, mean, std, train):
+    def _run_forward(self, x, normalize, mean, std, train, defer_join=False):
         x = self._check_input(x)
         B, _, H, W = x.shape
         plan = self._plan(B, H, W)
@@ -522,8 +522,12 @@ class SegNet(nn.Module):
                 L.check(L.lib().octseg_net_forward(plan.handle, L.ptr(self.arena.data), L.ptr(self.bn_buffers),
                                                    L.ptr(plan.ws(x.device)), L.ptr(gin), L.ptr(gout), int(bool(normalize)), m, s, 0,
                                                    L.stream_ptr()))
+            if defer_join:               # forward_async: the caller joins later, other nets' replays run beside this one
+                return (gout, gstream), plan
             cur.wait_stream(gstream)
             return gout.clone(), plan
+        if defer_join:
+            raise RuntimeError('forward_async needs eval mode and use_graph=True (the replay runs on the plan\'s own stream)')
         logits = torch.empty((B, self.classes, H, W), dtype=torch.float32, device=x.device)
         L.check(L.lib().octseg_net_forward(plan.handle, L.ptr(self.arena.data), L.ptr(self.bn_buffers), L.ptr(plan.ws(x.device)),
                                            L.ptr(x), L.ptr(logits), int(bool(normalize)), m, s, int(bool(train)),
@@ -536,6 +540,21 @@ class SegNet(nn.Module):
     def forward(self, x, normalize=False, mean=None, std=None):
         logits, _ = self._run_forward(x, normalize, mean, std, self.training)
         return logits
+
+    def forward_async(self, x, normalize=False, mean=None, std=None):
+        """Serving (eval, use_graph=True): enqueue this net's replayed forward on the plan's own stream and return at once.  Several nets
+        started this way run side by side -- at one frame per step their grids fill a fraction of the chip each (the three-net ensemble
+        of src/predict.py:61-101).  `forward_join(handle)` makes the current stream wait and returns the logits."""
+        if self.training:
+            raise RuntimeError('forward_async is a serving call: switch the net to eval()')
+        handle, _ = self._run_forward(x, normalize, mean, std, False, defer_join=True)
+        return handle
+
+    @staticmethod
+    def forward_join(handle):
+        gout, gstream = handle
+        torch.cuda.current_stream(gout.device).wait_stream(gstream)
+        return gout.clone()
 
     def dice(self, plan, logits, target):
         target = target.contiguous()

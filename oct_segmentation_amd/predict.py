@@ -131,7 +131,8 @@ def segment(images, masks, output_size, classes, models_dir, device='cuda', batc
             use_graph=False):
     """predict.py:61-101.  images: list of PIL images; masks: list of zero arrays [H_out, W_out, 4].
 
-    Every model runs once (the reference runs FC_LC once per class), in batches; thresholding, the nearest resize to
+    Every model runs once (the reference runs FC_LC once per class), in batches (with ``use_graph`` the nets' replayed forwards side by
+    side); thresholding, the nearest resize to
     ``output_size`` and the 4-channel mask assembly happen on the GPU (``octseg_mask_assemble``); one D2H copy of the
     assembled 0/1 stack at the end instead of one logits tensor per frame and class."""
     from . import _lib as L
@@ -140,16 +141,32 @@ def segment(images, masks, output_size, classes, models_dir, device='cuda', batc
     # to tuple(output_size): the assignment into mask[:, :, c] only works for square sizes, and so do the extents below
     oh, ow = masks[0].shape[0], masks[0].shape[1]
     stack = torch.zeros((n, oh, ow, 4), dtype=torch.float32, device=device)
-    cache, tables = {}, {}
+    cache, tables, loaded = {}, {}, {}
+    for class_name in classes:     # every distinct model once: weights and the preprocessed frames at that model's input size
+        model_dir = os.path.join(models_dir, MODELS_META[class_name]['model_dir'])
+        if model_dir not in loaded:
+            model, cfg = load_model(model_dir, device, compute_dtype, use_graph=use_graph)
+            loaded[model_dir] = (model, np.array([preprocessing_img(img, cfg['input_size']) for img in images]))
+    parts = {d: [] for d in loaded}
+    for i in range(0, n, batch_size):
+        if use_graph:
+            # the replayed forwards of the (up to three) nets are started together, each on its plan's own stream, and joined in order:
+            # at one frame per step a single net fills a fraction of the chip (SegNet.forward_async)
+            handles = {}
+            for d, (model, batch) in loaded.items():
+                x = torch.as_tensor(np.ascontiguousarray(batch[i:i + batch_size].transpose((0, 3, 1, 2))), dtype=torch.float32).to(model.model.device)
+                handles[d] = model.model.eval().forward_async(x, normalize=False)
+            for d, h in handles.items():
+                parts[d].append(loaded[d][0].model.forward_join(h))
+        else:
+            for d, (model, batch) in loaded.items():
+                parts[d].append(model.predict_logits(batch[i:i + batch_size]))
+    for d in loaded:
+        cache[d] = torch.cat(parts[d], dim=0)
+    del loaded
     for class_name in classes:
         meta = MODELS_META[class_name]
         model_dir = os.path.join(models_dir, meta['model_dir'])
-        if model_dir not in cache:
-            model, cfg = load_model(model_dir, device, compute_dtype, use_graph=use_graph)
-            batch = np.array([preprocessing_img(img, cfg['input_size']) for img in images])
-            logits = [model.predict_logits(batch[i:i + batch_size]) for i in range(0, n, batch_size)]
-            cache[model_dir] = torch.cat(logits, dim=0)
-            del model
         z = cache[model_dir]
         ch = meta['index'] if z.shape[1] > 1 else 0
         key = (z.shape[2], z.shape[3])
