@@ -14,6 +14,8 @@
  *                                      .predict's bare self.model(x) (normalize=0, model.py:192)
  *   octseg_dice_forward                smp.losses.DiceLoss(MULTILABEL_MODE, from_logits=True)
  *                                      (model.py:55,81,115) + smp.metrics.get_stats (utils.py:19-23)
+ *   octseg_plan_set_loss               the choice of criterion at model.py:55 (the reference always builds DiceLoss; north_star also
+ *                                      names BCE): Dice | torch.nn.functional.binary_cross_entropy_with_logits | their sum
  *   octseg_net_backward                loss.backward() that Lightning runs after training_step
  *                                      (model.py:73-95, train.py:130-133)
  *   octseg_net_train_step              training_step + loss.backward() as one call, optionally one replayed hipGraph (model.py:73-95)
@@ -141,7 +143,8 @@ int octseg_plan_set_dropout(octseg_plan* plan, const float* keep_dev);
 int octseg_plan_set_graph(octseg_plan* plan, int enable);
 
 /* image: NCHW f32 [B,3,H,W]; logits: NCHW f32 [B,classes,H,W]; mean/std: 3 host floats (normalize=1).
- * train=1: batch statistics, running buffers updated, activations kept for backward. */
+ * train=1: batch statistics, running buffers updated, activations kept for backward -- and `image` itself must stay valid and
+ * unchanged until that backward has been enqueued: the stem's weight gradient gathers the frame again instead of saving an im2col copy. */
 int octseg_net_forward(octseg_plan* plan, const float* params, float* buffers, void* workspace,
                        const float* image, float* logits, int normalize, const float* mean,
                        const float* stdv, int train, void* stream);
@@ -165,6 +168,13 @@ int octseg_augment(const float* img, const float* mask, float* img_out, float* m
  * min(floor(i * (1 / (out / in))), in - 1), what the reference's cv2.resize call computes); null = floor((i + 0.5) * H / out_h). */
 int octseg_mask_assemble(const float* logits, int N, int classes, int H, int W, int ch, float* out, int out_h, int out_w,
                          int out_channels, int out_ch, const int* row_index, const int* col_index, void* stream);
+
+/* Criterion evaluated by octseg_dice_forward / octseg_net_train_step and differentiated by the backward entry points.
+ * OCTSEG_LOSS_DICE (default) = smp.losses.DiceLoss(MULTILABEL_MODE, from_logits=True), the reference's (model.py:55);
+ * OCTSEG_LOSS_BCE = torch.nn.functional.binary_cross_entropy_with_logits(logits, target) (reduction 'mean' over every element);
+ * OCTSEG_LOSS_DICE_BCE = their unweighted sum.  All three come out of the ONE pass over logits / target that also counts tp/fp/fn/tn. */
+typedef enum { OCTSEG_LOSS_DICE = 0, OCTSEG_LOSS_BCE = 1, OCTSEG_LOSS_DICE_BCE = 2 } octseg_loss_kind;
+int octseg_plan_set_loss(octseg_plan* plan, int kind);
 
 /* loss: device f32 scalar; stats: device int64 [B][classes][4] = tp, fp, fn, tn (nullable). */
 int octseg_dice_forward(octseg_plan* plan, void* workspace, const float* logits, const float* target,

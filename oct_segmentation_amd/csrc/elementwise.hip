@@ -939,11 +939,14 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float* z = a.logits + ((size_t)b * a.C + c) * a.HW;
   const float* t = a.target + ((size_t)b * a.C + c) * a.HW;
-  double sI = 0, sS = 0, sT = 0;
+  double sI = 0, sS = 0, sT = 0, sB = 0;
   long long tp = 0, np = 0, nt = 0;
+  const bool want_bce = a.loss_kind != LOSS_DICE;
   auto one = [&](float zi, float ti) {
     const float p = sigmoid_acc(zi);
     sI += (double)(p * ti); sS += (double)(p + ti); sT += (double)ti;
+    // binary_cross_entropy_with_logits, ATen's stable form: (1 - t) z + max(-z, 0) + log(1 + exp(-|z|))
+    if (want_bce) sB += (double)((1.0f - ti) * zi + fmaxf(-zi, 0.f) + log1pf(expf(-fabsf(zi))));
     const int pred = p > 0.5f;
     const int tt = (long long)ti != 0;  // .long() truncation as get_stats does
     tp += pred & tt; np += pred; nt += tt;
@@ -958,11 +961,13 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.HW; i += (size_t)gridDim.x * blockDim.x) one(z[i], t[i]);
   }
   sI = block_sum<double>(sI, dred); sS = block_sum<double>(sS, dred); sT = block_sum<double>(sT, dred);
+  if (want_bce) sB = block_sum<double>(sB, dred);
   tp = block_sum<long long>(tp, ired); np = block_sum<long long>(np, ired); nt = block_sum<long long>(nt, ired);
   if (threadIdx.x == 0) {
     // per-image replica of the sums (3872 blocks adding to the same three doubles serialised in the L2: 0.15 ms)
-    double* rep = a.sums + (size_t)(1 + b) * a.C * 3;
-    atomicAdd(rep + c * 3 + 0, sI); atomicAdd(rep + c * 3 + 1, sS); atomicAdd(rep + c * 3 + 2, sT);
+    double* rep = a.sums + (size_t)(1 + b) * a.C * DICE_NS;
+    atomicAdd(rep + c * DICE_NS + 0, sI); atomicAdd(rep + c * DICE_NS + 1, sS); atomicAdd(rep + c * DICE_NS + 2, sT);
+    if (want_bce) atomicAdd(rep + c * DICE_NS + 3, sB);
     if (a.stats) {
       unsigned long long* s = (unsigned long long*)(a.stats + ((size_t)b * a.C + c) * 4);
       atomicAdd(s + 0, (unsigned long long)tp);
@@ -973,18 +978,21 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceArgs a) {
 }
 __global__ void dice_finalize_kernel(const DiceArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double loss = 0.0;
+    double loss = 0.0, bce = 0.0;
     for (int c = 0; c < a.C; ++c) {
-      for (int k = 0; k < 3; ++k) {   // totals = the per-image replicas in image order
+      for (int k = 0; k < DICE_NS; ++k) {   // totals = the per-image replicas in image order
         double tot = 0.0;
-        for (int b = 0; b < a.B; ++b) tot += a.sums[(size_t)(1 + b) * a.C * 3 + c * 3 + k];
-        a.sums[c * 3 + k] = tot;
+        for (int b = 0; b < a.B; ++b) tot += a.sums[(size_t)(1 + b) * a.C * DICE_NS + c * DICE_NS + k];
+        a.sums[c * DICE_NS + k] = tot;
       }
-      const float I = (float)a.sums[c * 3], S = (float)a.sums[c * 3 + 1], T = (float)a.sums[c * 3 + 2];
+      const float I = (float)a.sums[c * DICE_NS], S = (float)a.sums[c * DICE_NS + 1], T = (float)a.sums[c * DICE_NS + 2];
       const float score = (2.0f * I) / fmaxf(S, 1e-7f);
       loss += (T > 0.f) ? (double)(1.0f - score) : 0.0;
+      bce += a.sums[c * DICE_NS + 3];
     }
-    *a.loss = (float)(loss / a.C);
+    const float dice = (float)(loss / a.C);
+    const float bcem = (float)(bce / ((double)a.B * a.C * (double)a.HW));   // reduction='mean' over every element
+    *a.loss = a.loss_kind == LOSS_DICE ? dice : a.loss_kind == LOSS_BCE ? bcem : dice + bcem;
     if (a.stats)
       for (int i = 0; i < a.B * a.C; ++i) {
         long long* s = a.stats + (size_t)i * 4;
@@ -993,12 +1001,13 @@ __global__ void dice_finalize_kernel(const DiceArgs a) {
   }
 }
 hipError_t launch_dice_fwd(const DiceArgs& a, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * 3 * a.C * (size_t)(1 + a.B), st);   // totals + one replica per image
+  hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * DICE_NS * a.C * (size_t)(1 + a.B), st);   // totals + one replica per image
   if (e != hipSuccess) return e;
   if (a.stats) {
     e = hipMemsetAsync(a.stats, 0, sizeof(long long) * 4 * a.B * a.C, st);
     if (e != hipSuccess) return e;
   }
+  if (a.loss_kind < LOSS_DICE || a.loss_kind > LOSS_DICE_BCE) return hipErrorInvalidValue;
   // 32 elements per thread: a workgroup ends in six block reductions and six atomics, which dominated at 8 per thread
   int chunks = (int)((a.HW + 256 * 32 - 1) / (256 * 32));
   if (chunks > 128) chunks = 128;
@@ -1016,6 +1025,8 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float g
   constexpr int MAXC = 16;                       // classes kept in registers (launch_dice_bwd checks C <= CP <= 16)
   constexpr int MAXV = MAXC / VEC;
   const size_t npix = (size_t)a.B * a.HW;
+  const bool want_dice = a.loss_kind != LOSS_BCE, want_bce = a.loss_kind != LOSS_DICE;
+  const float bce_scale = grad_scale / ((float)a.B * (float)a.C * (float)a.HW);
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
     const size_t b = p / a.HW, i = p - b * a.HW;
     float d[MAXC];
@@ -1023,8 +1034,12 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float g
     for (int c = 0; c < MAXC; ++c) {
       d[c] = 0.f;
       if (c < a.C) {
-        const float I = (float)a.sums[c * 3], S = (float)a.sums[c * 3 + 1], Tt = (float)a.sums[c * 3 + 2];
-        if (Tt > 0.f) {
+        const float I = (float)a.sums[c * DICE_NS], S = (float)a.sums[c * DICE_NS + 1], Tt = (float)a.sums[c * DICE_NS + 2];
+        if (want_bce) {   // d/dz mean(bce_with_logits) = (sigmoid(z) - t) / numel
+          const float z = a.logits[(b * a.C + c) * a.HW + i], t = a.target[(b * a.C + c) * a.HW + i];
+          d[c] = (sigmoid_acc(z) - t) * bce_scale;
+        }
+        if (want_dice && Tt > 0.f) {
           const float z = a.logits[(b * a.C + c) * a.HW + i], t = a.target[(b * a.C + c) * a.HW + i];
           // dp/dz = p (1 - p) = e / (1 + e)^2 with e = exp(-|z|): autograd of logsigmoid(z).exp() gives exactly this
           // product (p * e/(1+e) for z >= 0, p * 1/(1+e) for z < 0).  Written as p * (1 - p) it vanishes for z > ~17
@@ -1034,7 +1049,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceArgs a, float g
           float dscore;  // d(2I / max(S, eps)) / dp
           if (S > 1e-7f) dscore = (2.0f * t * S - 2.0f * I) / (S * S);
           else dscore = 2.0f * t / 1e-7f;
-          d[c] = -dscore * dpdz * grad_scale / (float)a.C;
+          d[c] += -dscore * dpdz * grad_scale / (float)a.C;
         }
       }
     }

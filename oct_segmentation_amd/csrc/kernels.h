@@ -136,10 +136,13 @@ hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const voi
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
                               const float* mean, const float* stdv, int normalize, hipStream_t st);
 
-// Dice loss (multilabel, from logits) + confusion counts, logits/target NCHW f32
+// Dice loss (multilabel, from logits) and / or mean binary cross-entropy with logits + confusion counts, logits/target NCHW f32
+constexpr int DICE_NS = 4;                                   // doubles per (image, class): I, S, T, BCE sum
+enum { LOSS_DICE = 0, LOSS_BCE = 1, LOSS_DICE_BCE = 2 };     // = octseg_loss_kind
 struct DiceArgs {
   const float* logits; const float* target; int B, C; size_t HW;
-  double* sums;        // [1 + B][C][3]: I, S, T totals, then per-image replicas (zeroed by the launcher)
+  int loss_kind;       // LOSS_*
+  double* sums;        // [1 + B][C][DICE_NS]: I, S, T, BCE totals, then per-image replicas (zeroed by the launcher)
   long long* stats;    // [B][C][4]: tp, fp, fn, tn (zeroed by the launcher), nullable
   float* loss;         // scalar
 };

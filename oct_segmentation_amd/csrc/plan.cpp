@@ -889,7 +889,7 @@ static int build_plan(octseg_plan* P) {
   }
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
-  P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * 3 * sizeof(double));   // totals + per-image replicas
+  P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * DICE_NS * sizeof(double));   // totals + per-image replicas
   P->ws_bytes = off;
   return OCTSEG_OK;
 }
@@ -1509,7 +1509,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   DiceArgs da;
   memset(&da, 0, sizeof(da));
   da.logits = logits; da.target = target; da.B = P->B; da.C = P->classes; da.HW = (size_t)P->H * P->W;
-  da.sums = (double*)(E.ws + P->dice_off);
+  da.sums = (double*)(E.ws + P->dice_off); da.loss_kind = P->loss_kind;
   HIPCHK(launch_dice_bwd(P->dtype, da, grad_scale, E.ws + P->dlogits_off, P->dlogits_C, E.st));
   int rc;
   for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
@@ -1891,7 +1891,7 @@ int octseg_dice_forward(octseg_plan* p, void* workspace, const float* logits, co
   DiceArgs a;
   memset(&a, 0, sizeof(a));
   a.logits = logits; a.target = target; a.B = p->B; a.C = p->classes; a.HW = (size_t)p->H * p->W;
-  a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss;
+  a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss; a.loss_kind = p->loss_kind;
   HIPCHK(launch_dice_fwd(a, (hipStream_t)stream));
   return OCTSEG_OK;
 }
@@ -1925,7 +1925,7 @@ int octseg_net_train_step(octseg_plan* p, const float* params, float* grads, flo
     DiceArgs a;
     memset(&a, 0, sizeof(a));
     a.logits = logits; a.target = target; a.B = p->B; a.C = p->classes; a.HW = (size_t)p->H * p->W;
-    a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss;
+    a.sums = (double*)((char*)workspace + p->dice_off); a.stats = stats; a.loss = loss; a.loss_kind = p->loss_kind;
     HIPCHK(launch_dice_fwd(a, st));
     Exec Eb{p, params, grads, nullptr, (char*)workspace, st, 1};
     return run_backward(Eb, logits, target, grad_scale);
@@ -1938,7 +1938,9 @@ int octseg_net_train_step(octseg_plan* p, const float* params, float* grads, flo
     if (p->tgraph_exec) { (void)hipGraphExecDestroy(p->tgraph_exec); p->tgraph_exec = nullptr; }
     p->tgraph_key = key; p->tgraph_seen = 0;
   }
-  if (p->tgraph_exec) { HIPCHK(hipGraphLaunch(p->tgraph_exec, st)); return OCTSEG_OK; }
+  // a replay repacks the UNFOLDED training weight images and rewrites the BatchNorm scale / shift in the workspace behind the host
+  // cache's back: drop the cache, or an eval forward of this plan would take the hit and run its folded epilogue on unfolded images
+  if (p->tgraph_exec) { HIPCHK(hipGraphLaunch(p->tgraph_exec, st)); p->packed_valid = false; return OCTSEG_OK; }
   if (p->tgraph_seen++ == 0) return body();   // eager warm-up: function attributes, job tables, side stream and events exist afterwards
   p->packed_valid = false;                    // the captured step must contain the weight packing (a replay meets new parameters)
   hipGraph_t g = nullptr;
@@ -1954,6 +1956,16 @@ int octseg_net_train_step(octseg_plan* p, const float* params, float* grads, flo
   (void)hipGraphDestroy(g);
   if (ie != hipSuccess) { p->tgraph_exec = nullptr; return fail(OCTSEG_HIP_ERROR, hipGetErrorString(ie)); }
   HIPCHK(hipGraphLaunch(p->tgraph_exec, st));
+  p->packed_valid = false;
+  return OCTSEG_OK;
+}
+// Loss behind octseg_dice_forward / the backward's dL/dlogits: smp DiceLoss (the reference, model.py:55), mean BCE-with-logits, or
+// their sum.  A captured training step holds the old kind's kernels' arguments: drop it.
+int octseg_plan_set_loss(octseg_plan* p, int kind) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  if (kind < LOSS_DICE || kind > LOSS_DICE_BCE) return fail(OCTSEG_BAD_ARG, "loss kind must be 0 (dice), 1 (bce) or 2 (dice + bce)");
+  if (kind != p->loss_kind && p->tgraph_exec) { (void)hipGraphExecDestroy(p->tgraph_exec); p->tgraph_exec = nullptr; p->tgraph_seen = 0; }
+  p->loss_kind = kind;
   return OCTSEG_OK;
 }
 int octseg_plan_set_train_graph(octseg_plan* p, int enable) {

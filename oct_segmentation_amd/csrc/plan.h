@@ -134,7 +134,8 @@ struct octseg_plan {
   size_t pool_idx_off = 0;                   // maxpool: window position of every maximum (1 byte per output element)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
-  size_t dice_off = 0;                       // double sums[1 + B][C][3]: totals, then one replica per image
+  int loss_kind = 0;                         // LOSS_DICE | LOSS_BCE | LOSS_DICE_BCE (octseg_plan_set_loss)
+  size_t dice_off = 0;                       // double sums[1 + B][C][DICE_NS]: totals, then one replica per image
   int col_tensor = -1;
   int dlogits_C = 16;
   double fwd_macs = 0;

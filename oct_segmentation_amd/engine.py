@@ -79,7 +79,9 @@ class _DiceStep(torch.autograd.Function):
     def forward(ctx, arena, net, image, target, normalize, mean, std):
         logits, loss, stats, plan = net._forward_loss(image, target, normalize, mean, std)
         ctx.net, ctx.plan, ctx.logits, ctx.target, ctx.generation = net, plan, logits, target, plan.generation
-        ctx.image = image   # the stem's weight gradient gathers the frame again in the backward: keep it alive
+        # the stem's weight gradient gathers the frame again in the backward: keep alive the CONTIGUOUS tensor the kernel read
+        # (for a channels_last / permuted input that is a copy made by _check_input, not `image` itself)
+        ctx.image = plan.stem_frame
         ctx.mark_non_differentiable(logits, stats)
         return loss, logits, stats
 
@@ -173,6 +175,9 @@ class SegNet(nn.Module):
         super().__init__()
         use_graph = bool(kwargs.pop('use_graph', False))   # eval forwards as replayed hipGraphs (serving)
         use_train_graph = bool(kwargs.pop('use_train_graph', False))
+        loss = kwargs.pop('loss', 'dice')   # 'dice' (the reference, model.py:55) | 'bce' | 'dice+bce': octseg_plan_set_loss
+        if loss not in L.LOSS_KINDS:
+            raise ValueError(f'loss must be one of {list(L.LOSS_KINDS)}, got {loss!r}')
         for k, v in kwargs.items():
             if k not in self._SMP_DEFAULTS:
                 raise TypeError(f'SegNet got an unexpected keyword argument {k!r}')
@@ -192,6 +197,7 @@ class SegNet(nn.Module):
         self.device = torch.device(device)
         self._plans = {}
         self.use_graph = use_graph
+        self.loss = loss
         # train_step_raw as ONE replayed hipGraph per (B, H, W) plan (octseg_net_train_step + octseg_plan_set_train_graph): the ~800
         # launches of a step cost the host tens of milliseconds to enqueue, which bounds small per-GPU batches; not with `exchange`
         self.use_train_graph = use_train_graph
@@ -400,7 +406,11 @@ class SegNet(nn.Module):
         key = (B, H, W)
         if key not in self._plans:
             self._plans[key] = _Plan(self.arch, self.encoder_name, self.classes, B, H, W, self.dtype_code)
-        return self._plans[key]
+        plan = self._plans[key]
+        if getattr(plan, 'loss', 'dice') != self.loss:     # the criterion is a property of the net; plans follow it
+            L.check(L.lib().octseg_plan_set_loss(plan.handle, L.LOSS_KINDS[self.loss]))
+            plan.loss = self.loss
+        return plan
 
     def fwd_macs(self, B, H, W):
         return L.lib().octseg_plan_fwd_macs(self._plan(B, H, W).handle)
@@ -496,6 +506,8 @@ class SegNet(nn.Module):
             plan.seen_version = ver
         if not train:
             plan.seen_buffers = bver
+        if train:
+            plan.stem_frame = x        # octseg.h: `image` must outlive the backward (the stem weight gradient reads it again)
         if self._has_dropout() and train:
             keep = self._draw_keep(B, H, W, x.device)
             plan.drop_keep = keep      # the backward of this step reads it too: keep it alive with the plan
@@ -516,6 +528,11 @@ class SegNet(nn.Module):
                                  torch.cuda.Stream(device=x.device))   # the legacy default stream cannot be captured
             gin, gout, gstream = plan.graph_io
             cur = torch.cuda.current_stream(x.device)
+            if getattr(plan, 'graph_pending', False):
+                # an earlier forward_async of this (net, shape) was never joined: its replay may still read gin / write gout
+                cur.wait_stream(gstream)
+                plan.graph_pending = False
+                warnings.warn('forward_async called again before forward_join: the earlier handle now aliases the new logits')
             gin.copy_(x)
             gstream.wait_stream(cur)
             with torch.cuda.stream(gstream):
@@ -523,7 +540,8 @@ class SegNet(nn.Module):
                                                    L.ptr(plan.ws(x.device)), L.ptr(gin), L.ptr(gout), int(bool(normalize)), m, s, 0,
                                                    L.stream_ptr()))
             if defer_join:               # forward_async: the caller joins later, other nets' replays run beside this one
-                return (gout, gstream), plan
+                plan.graph_pending = True
+                return (gout, gstream, plan), plan
             cur.wait_stream(gstream)
             return gout.clone(), plan
         if defer_join:
@@ -552,8 +570,9 @@ class SegNet(nn.Module):
 
     @staticmethod
     def forward_join(handle):
-        gout, gstream = handle
+        gout, gstream, plan = handle
         torch.cuda.current_stream(gout.device).wait_stream(gstream)
+        plan.graph_pending = False
         return gout.clone()
 
     def dice(self, plan, logits, target):

@@ -23,11 +23,43 @@ CLASS_IDS = {'Lumen': 1, 'Fibrous cap': 2, 'Lipid core': 3, 'Vasa vasorum': 4}
 
 class DiceLoss:
     """Marker object kept for API parity (``self.loss_fn``); the loss itself is fused into the
-    engine (``SegNet.dice_step``): smp DiceLoss(MULTILABEL_MODE, from_logits=True), model.py:55."""
+    engine (``SegNet.dice_step``): smp DiceLoss(MULTILABEL_MODE, from_logits=True), model.py:55.
+    ``kind``: 'dice' (the reference) | 'bce' (F.binary_cross_entropy_with_logits, mean) | 'dice+bce' (their sum) --
+    evaluated and differentiated by the same fused pass (octseg_plan_set_loss)."""
     mode = 'multilabel'
     from_logits = True
     smooth = 0.0
     eps = 1e-7
+
+    def __init__(self, kind='dice'):
+        self.kind = kind
+
+
+class _LiveRangeOptimizer:
+    """torch optimizer over the whole arena of a net with never-run parameters (PSPNet keeps encoder.layer3 / layer4 in its
+    state_dict, smp encoder_depth 3).  In the reference those parameters have ``grad is None`` and every torch optimizer skips
+    them; here the arena is ONE parameter whose gradient is zero there, so weight decay (and Adam's moments) would still move
+    them: the dead ranges are put back after every step."""
+
+    def __init__(self, opt, net):
+        self._opt, self._net = opt, net
+        lo, self._dead = 0, []
+        for a, b in net.live_ranges:
+            if a > lo:
+                self._dead.append((lo, a))
+            lo = b
+        if lo < net.param_numel:
+            self._dead.append((lo, net.param_numel))
+
+    def step(self, *args, **kwargs):
+        keep = [self._net.arena.data[a:b].clone() for a, b in self._dead]
+        out = self._opt.step(*args, **kwargs)
+        for (a, b), k in zip(self._dead, keep):
+            self._net.arena.data[a:b] = k
+        return out
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
 
 
 class FusedOptimizer:
@@ -71,12 +103,12 @@ class OCTSegmentationModel(nn.Module):
     def __init__(self, arch, encoder_name, model_name, in_channels, classes, lr=0.0001, data_dir=None,
                  weight_decay=0.0001, optimizer_name='Adam', input_size=512, img_save_interval=1,
                  save_wandb_media=False, device='cuda', compute_dtype=torch.bfloat16, fused_optimizer=True, encoder_weights=None,
-                 defer_metrics=False, **kwargs):
+                 defer_metrics=False, loss='dice', **kwargs):
         super().__init__()
         # **kwargs go to the network factory as in the reference (model.py:38-44 -> smp.create_model); SegNet rejects what it
         # does not implement.  encoder_weights: see SegNet (the reference's smp default 'imagenet' needs a download).
         self.model = SegNet(arch, encoder_name, encoder_weights=encoder_weights, in_channels=in_channels, classes=len(classes),
-                            device=device, compute_dtype=compute_dtype, **kwargs)
+                            device=device, compute_dtype=compute_dtype, loss=loss, **kwargs)
         self.classes = list(classes)
         self.data_dir = data_dir
         self.epoch = 0
@@ -92,7 +124,7 @@ class OCTSegmentationModel(nn.Module):
         self.defer_metrics = bool(defer_metrics)
         self._deferred = {'train': DeferredMetrics(), 'test': DeferredMetrics()}
         self.validation_best_metrics = {}
-        self.loss_fn = DiceLoss()
+        self.loss_fn = DiceLoss(loss)
         self.model_name = model_name
         self.lr, self.weight_decay, self.optimizer = lr, weight_decay, optimizer_name
         self.input_size = input_size
@@ -150,7 +182,10 @@ class OCTSegmentationModel(nn.Module):
             return FusedOptimizer(self.model, self.optimizer, self.lr, self.weight_decay)
         cls = {'SGD': torch.optim.SGD, 'RMSprop': torch.optim.RMSprop, 'RAdam': torch.optim.RAdam,
                'Adam': torch.optim.Adam}[self.optimizer]
-        return cls(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        opt = cls(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        if len(self.model.live_ranges) != 1 or self.model.live_ranges[0] != (0, self.model.param_numel):
+            return _LiveRangeOptimizer(opt, self.model)
+        return opt
 
     # ---- model.py:183-200: NHWC numpy in, no normalisation, sigmoid > 0.5, NHWC numpy out.  The threshold and the
     # NCHW -> NHWC transpose run in the engine's serving epilogue (octseg_mask_assemble at identity size): one D2H copy of

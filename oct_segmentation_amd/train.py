@@ -77,7 +77,9 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
     for epoch in range(1, int(cfg['epochs']) + 1):
         model.train()
         model.training_step_outputs.clear()
+        n_train = 0
         for img, mask in train_batches:
+            n_train += 1
             if cfg.get('use_augmentation', False):   # train.yaml use_augmentation (dataset.py:119-123), on the GPU
                 if aug_rng is None:
                     aug_rng = np.random.default_rng(augment_seed)
@@ -90,6 +92,9 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
                                                      grad_scale=1.0 / world, exchange=exchange)
             opt.step()
             model.record_step('train', stats, loss)
+        if n_train == 0:
+            raise ValueError(f'fit(): train_batches yielded no batches in epoch {epoch}; pass a re-iterable (a list or a DataLoader), '
+                             f'not a generator that is exhausted after the first epoch')
         row = {'epoch': epoch}
         val_outputs = None
         if val_batches is not None:   # Lightning runs the validation loop before on_train_epoch_end
@@ -100,6 +105,9 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
                 out = model.validation_step(batch)
                 vloss.append(out['val/loss'].detach().reshape(1))   # self.log('val/loss', on_epoch=True): batch-size-weighted mean
                 vcount.append(batch[0].shape[0])
+            if not vloss:
+                raise ValueError(f'fit(): val_batches yielded no batches in epoch {epoch}; pass a re-iterable (a list or a DataLoader), '
+                                 f'not a generator that is exhausted after the first epoch')
             w = torch.tensor(vcount, dtype=torch.float64)
             row['val/loss'] = float((torch.cat(vloss).double().cpu() * w).sum() / max(float(w.sum()), 1.0))   # one D2H per epoch
             if model_dir is not None and rank0 and (best_val is None or row['val/loss'] < best_val):

@@ -24,6 +24,6 @@ known smp model sizes, state_dict key names follow the smp/torchvision module
 tree, Dice/metric closed-form known answers (tests/test_oracle.py).
 """
 from .nets import create_model, get_preprocessing_params, ENCODER_CHANNELS  # noqa: F401
-from .losses import DiceLoss, soft_dice_score  # noqa: F401
+from .losses import DiceBCELoss, DiceLoss, bce_with_logits, soft_dice_score  # noqa: F401
 from .metrics import get_stats, iou_score, f1_score, precision, sensitivity, get_metrics  # noqa: F401
 from .model import OracleOCTSegmentationModel  # noqa: F401

@@ -40,3 +40,21 @@ class DiceLoss(torch.nn.Module):
         mask = y_true.sum(dims) > 0
         loss = loss * mask.to(loss.dtype)
         return loss.mean()
+
+
+def bce_with_logits(y_pred, y_true):
+    """The BCE half of north_star's "Dice/BCE loss+grad": ``torch.nn.functional.binary_cross_entropy_with_logits`` with its defaults
+    (reduction 'mean' over every element).  The reference itself builds DiceLoss only (``model.py:55``); this is the oracle of the
+    engine's ``loss='bce'`` / ``'dice+bce'`` switch."""
+    return F.binary_cross_entropy_with_logits(y_pred, y_true.type_as(y_pred))
+
+
+class DiceBCELoss(torch.nn.Module):
+    """Unweighted sum of the two (``loss='dice+bce'``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.dice = DiceLoss()
+
+    def forward(self, y_pred, y_true):
+        return self.dice(y_pred, y_true) + bce_with_logits(y_pred, y_true)

@@ -389,3 +389,44 @@ def test_sweep_architectures_through_the_model_class(cuda, tmp_path, arch):
     m2, _ = load_model(str(tmp_path), 'cuda', torch.float16)          # serving dtype
     out = m2.predict(np.zeros((1, 64, 64, 3), np.float32), 'cuda')
     assert out.shape == (1, 64, 64, 2) and set(np.unique(out)) <= {0.0, 1.0}
+
+
+def test_eval_forward_after_a_replayed_training_step_through_the_c_abi(cuda):
+    """a replay of octseg_net_train_step repacks the UNFOLDED training weight images inside the graph, behind the host's
+    pack cache.  A C-ABI caller's sequence eval forward -> replayed training steps -> eval forward (no octseg_plan_params_changed in
+    between; the Python wrapper always issues one) must not take a stale cache hit: the second eval forward has to equal the one after
+    an explicit invalidation."""
+    import ctypes as C
+    from oct_segmentation_amd import _lib as L
+    from oct_segmentation_amd.engine import SegNet
+    net = SegNet('unet', 'resnet18', classes=1, device=cuda, compute_dtype=torch.bfloat16, seed=5)
+    img, mask = (t.to(cuda) for t in make_batch(2, 1, 64, seed=3))
+    plan = net._plan(2, 64, 64)
+    lib, ws = L.lib(), plan.ws(cuda)
+    m, s = (C.c_float * 3)(0.485, 0.456, 0.406), (C.c_float * 3)(0.229, 0.224, 0.225)
+    logits = torch.empty(2, 1, 64, 64, device=cuda)
+    loss = torch.empty((), device=cuda)
+    stats = torch.empty(2, 1, 4, dtype=torch.int64, device=cuda)
+    grads = torch.zeros_like(net.arena.data)
+    st = torch.cuda.Stream(device=cuda)
+
+    def eval_fwd():
+        out = torch.empty_like(logits)
+        with torch.cuda.stream(st):
+            L.check(lib.octseg_net_forward(plan.handle, L.ptr(net.arena.data), L.ptr(net.bn_buffers), L.ptr(ws), L.ptr(img), L.ptr(out), 1, m, s, 0,
+                                           L.stream_ptr()))
+        st.synchronize()
+        return out
+
+    torch.cuda.synchronize()
+    eval_fwd()                                                          # folded eval images cached (packed_fold = 1)
+    L.check(lib.octseg_plan_set_train_graph(plan.handle, 1))
+    for _ in range(4):                                                  # eager warm-up, capture + launch, two replays
+        with torch.cuda.stream(st):
+            L.check(lib.octseg_net_train_step(plan.handle, L.ptr(net.arena.data), L.ptr(grads), L.ptr(net.bn_buffers), L.ptr(ws), L.ptr(img),
+                                              L.ptr(mask), L.ptr(logits), L.ptr(loss), L.ptr(stats), 1, m, s, 1.0, L.stream_ptr()))
+        st.synchronize()
+    a = eval_fwd()                                                      # no params_changed: must repack by itself
+    L.check(lib.octseg_plan_params_changed(plan.handle))
+    b = eval_fwd()
+    assert torch.isfinite(a).all() and torch.equal(a, b)

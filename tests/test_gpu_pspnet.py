@@ -177,3 +177,29 @@ def test_pspnet_dead_stages_are_left_alone_by_the_optimizer(cuda):
             d = (sd[k].cpu() - v).abs()
             # Adam's first step is lr * g / (|g| + eps): an element whose gradient is rounding noise may move by lr in either direction
             assert d.max().item() <= 2.2e-3 and d.mean().item() <= 5e-5, (k, d.max().item(), d.mean().item())
+
+
+def test_pspnet_dead_stages_under_a_torch_optimizer(cuda):
+    """with fused_optimizer=False the arena is ONE nn.Parameter whose gradient is zero over the never-run stages, so torch's
+    weight decay would still move them (in the reference their grad is None and the optimizer skips them).  configure_optimizers wraps
+    the torch optimizer so that the dead ranges come back bit-identical after every step, for every optimizer kind."""
+    from oct_segmentation_amd.model import OCTSegmentationModel
+    img, mask = make_batch(3, 1, 64, seed=8)
+    for name in ('Adam', 'SGD', 'RMSprop', 'RAdam'):
+        m = OCTSegmentationModel('PSPNet', 'resnet18', 'p', 3, ['Lumen'], lr=1e-3, weight_decay=1e-2, optimizer_name=name, device=cuda,
+                                 compute_dtype=torch.float32, fused_optimizer=False)
+        m.train()
+        before = m.model.state_dict()
+        opt = m.configure_optimizers()
+        for _ in range(2):
+            opt.zero_grad()
+            m.training_step((img.to(cuda), mask.to(cuda)))['loss'].backward()
+            opt.step()
+        after = m.model.state_dict()
+        moved = 0
+        for k, v in before.items():
+            if k.startswith('encoder.layer3.') or k.startswith('encoder.layer4.'):
+                assert torch.equal(after[k], v), (name, k)
+            elif v.dtype.is_floating_point and 'running' not in k and k.endswith('weight'):
+                moved += int(not torch.equal(after[k], v))
+        assert moved > 10, name          # the live parameters did step

@@ -18,7 +18,7 @@ for i in range(1,5):
     if not fs: print('pass',i,'no output'); continue
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(fs[0])):
-        if any(k in r['Kernel_Name'] for k in ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad')):
+        if any(k in r['Kernel_Name'] for k in ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad', 'thin_')):
             a=agg[r['Counter_Name']]; a[0]+=float(r['Counter_Value']); a[1]+=1
     for k,v in agg.items(): print('${tag}',k, v[0]/v[1], 'per launch,', v[1], 'launches')
 PY
