@@ -298,6 +298,9 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: --batch frames per GPU whatever N; strong: the global batch stays --batch, every GPU gets batch/N frames')
     ap.add_argument('--allreduce-slices', type=int, default=3, help='gradient-arena slices all-reduced beside the backward (N > 1)')
+    ap.add_argument('--allreduce-dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='dtype of the gradients on the wire (N > 1): bf16 halves the bytes of the per-link-bound xGMI ring')
+    ap.add_argument('--loss', default='dice', choices=['dice', 'bce', 'dice+bce'], help="criterion (the reference's is Dice, model.py:55)")
     ap.add_argument('--dtype', default=None, choices=['bf16', 'fp32', 'fp16'], help='default: bf16 (training workloads), fp16 (ensemble)')
     ap.add_argument('--optimizer', default='Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -347,7 +350,8 @@ def main():
     if os.environ.get('OCTSEG_LIB'):   # A/B of two builds of the library on one box (tools/ab_perf.sh); the default is the in-tree build
         L.LIB_PATH = os.path.abspath(os.environ['OCTSEG_LIB'])
     from oct_segmentation_amd.model import OCTSegmentationModel
-    from oct_segmentation_amd.parallel import GradientExchange, broadcast_buffers, broadcast_parameters, shard_range
+    from oct_segmentation_amd.parallel import (GradientExchange, GradientExchangeError, broadcast_buffers, broadcast_parameters,
+                                               exit_on_exchange_failure, shard_range)
     from synth import make_batch
     import ctypes as C
 
@@ -362,7 +366,7 @@ def main():
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     names = ['Lumen', 'Fibrous cap', 'Lipid core', 'Vasa vasorum'][:classes]
     model = OCTSegmentationModel(arch, enc, 'bench', 3, names, lr=1e-5, weight_decay=0.0, optimizer_name=args.optimizer,
-                                 input_size=S, device=dev, compute_dtype=cdt, seed=1234)
+                                 input_size=S, device=dev, compute_dtype=cdt, seed=1234, loss=args.loss)
     model.train()
     net = model.model
     net.use_train_graph = bool(args.train_graph)
@@ -372,7 +376,7 @@ def main():
     if dp:
         broadcast_parameters(net)
         if not no_exch:
-            exchange = GradientExchange(net, nslices=args.allreduce_slices)
+            exchange = GradientExchange(net, nslices=args.allreduce_slices, wire_dtype=args.allreduce_dtype)
     opt = model.configure_optimizers()
     img, mask = make_batch(B, classes, S, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)
@@ -381,8 +385,11 @@ def main():
         if dp and not no_bcast:
             broadcast_buffers(net)  # torch-DDP broadcast_buffers=True
         # grad_scale 1/world + SUM all-reduce == DDP's gradient mean; the all-reduce runs slice by slice beside the backward
-        loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
-                                                 grad_scale=1.0 / world, exchange=exchange)
+        try:
+            loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
+                                                     grad_scale=1.0 / world, exchange=exchange)
+        except GradientExchangeError as e:     # the process group is aborted: leave non-zero, torchrun takes the job down
+            exit_on_exchange_failure(e)
         opt.step()
         return loss
 
@@ -451,7 +458,7 @@ def main():
         peak = 2500.0 if args.dtype == 'bf16' else 157.3
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         out = {
-            'metric': 'OCT frames/sec (704x704, bf16) fwd+bwd',
+            'metric': f'OCT frames/sec ({S}x{S}, {args.dtype}) fwd+bwd',
             'value': round(frames / dt, 3),
             'unit': 'frames/s',
             'n_gpus': world,
@@ -463,7 +470,7 @@ def main():
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic OCT-shaped frames (seeded), random-init weights',
-            'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+Dice+bwd+allreduce+{args.optimizer}',
+            'config': {'workload': f'{arch}/{enc} {classes}-class {S}x{S}, batch {B}/GPU, fwd+{ {"dice": "Dice", "bce": "BCE", "dice+bce": "Dice+BCE"}[args.loss] }+bwd+allreduce{"(bf16)" if args.allreduce_dtype == "bf16" else ""}+{args.optimizer}',
                        'global_batch': global_batch, 'parallelism': f'dp{world}', 'gmac_fwd_per_frame': round(macs / 1e9, 2)},
             'loss': round(loss_val, 6),
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3),

@@ -12,11 +12,46 @@ per-tensor hooks or copies into bucket buffers).  ``allreduce_gradients`` is the
 the backward).
 """
 import ctypes as C
+import os
+import sys
 
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
+
+
+class GradientExchangeError(RuntimeError):
+    """A collective of the step failed on this rank.  The process group has been ABORTED (peers blocked in a collective this rank
+    never joined fail too instead of hanging): the process cannot take part in another step and should exit non-zero so that the
+    launcher (torchrun) restarts the job from a checkpoint -- ``exit_on_exchange_failure`` does that."""
+
+
+def abort_process_group():
+    """Tear the default group down without waiting for outstanding collectives: ncclCommAbort (= RCCL's) through torch's
+    ``_abort_process_group`` / ``ProcessGroupNCCL.abort``; ``destroy_process_group`` is NOT an abort -- it flushes outstanding work first
+    and can itself block on a peer that is stuck.  gloo (CPU tests) has no abort: its group is destroyed."""
+    if not dist.is_initialized():
+        return 'not initialised'
+    try:
+        if dist.get_backend() == 'nccl':
+            from torch.distributed import distributed_c10d as c10d
+            if hasattr(c10d, '_abort_process_group'):
+                c10d._abort_process_group()
+                return 'aborted'
+            c10d._get_default_group()._get_backend(torch.device('cuda')).abort()
+            return 'aborted'
+        dist.destroy_process_group()
+        return 'destroyed'
+    except Exception as e:   # noqa: BLE001 -- already on the failure path
+        return f'abort failed: {e!r}'
+
+
+def exit_on_exchange_failure(err, code=13):
+    """What a training driver does with a GradientExchangeError: say so on stderr and leave with a non-zero code WITHOUT running
+    interpreter shutdown (destructors of an aborted communicator can block) -- a fresh process is the only clean state."""
+    print(f'[octseg] rank {os.environ.get("RANK", "0")}: {err}; exiting with code {code}', file=sys.stderr, flush=True)
+    os._exit(code)
 
 
 def _all_reduce_sum(t):
@@ -38,8 +73,15 @@ class GradientExchange:
 
     On return the caller's stream waits for every collective: ``net.arena.grad`` holds the averaged gradients."""
 
-    def __init__(self, net, nslices=3):
-        self.net, self.nslices = net, int(nslices)
+    def __init__(self, net, nslices=3, wire_dtype='fp32'):
+        """``wire_dtype='bf16'``: every slice is cast to bfloat16 on the communication stream, summed by the collective in bf16 and
+        written back to the fp32 arena -- half the bytes on the per-link-bound xGMI ring (136 instead of 272 MB for U-Net++/resnet101,
+        SURVEY section 5).  The cast runs beside the backward like the collective itself; the sum of W bf16 values carries ~3 significant
+        digits, which the reference's fp32 DDP buckets do not lose: opt-in."""
+        if wire_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"wire_dtype must be 'fp32' or 'bf16', got {wire_dtype!r}")
+        self.net, self.nslices, self.wire_dtype = net, int(nslices), wire_dtype
+        self._wire = torch.empty(net.param_numel, dtype=torch.bfloat16, device=net.device) if wire_dtype == 'bf16' else None
         self.comm = torch.cuda.Stream(device=net.device)
         self.fired = []          # (slice, begin, end) in completion order of the last step (tests / diagnostics)
         self._works = []
@@ -54,7 +96,16 @@ class GradientExchange:
                 return            # a collective already failed: issue no more, peers are released by the abort below
             g = self.net._grad_arena[begin:end]
             with torch.cuda.stream(self.comm):
-                w = _all_reduce_sum(g)
+                if self._wire is not None:
+                    h = self._wire[begin:end]      # persistent buffer: no allocator traffic across streams
+                    h.copy_(g)
+                    w = _all_reduce_sum(h)
+                    if w is not None:
+                        w.wait()                   # stream-ordered on comm (no host block): the copy back follows the collective
+                    g.copy_(h)
+                    w = None
+                else:
+                    w = _all_reduce_sum(g)
             if w is not None:
                 self._works.append(w)
         except BaseException as e:   # noqa: BLE001 -- must not propagate into the C caller
@@ -73,13 +124,11 @@ class GradientExchange:
                                                    C.c_void_p(self.comm.cuda_stream), self._cb, None))
         if self._error is not None:
             # some slices were reduced, some were not: this rank cannot finish the step and its peers may be blocked inside a
-            # collective it never joined -- tear the group down (nccl: abort) so that they fail too instead of hanging
+            # collective it never joined -- ABORT the communicator (not destroy_process_group, which waits for outstanding work and
+            # can block on exactly those peers) so that they fail too instead of hanging; the caller must exit (GradientExchangeError)
             err = self._error
-            try:
-                dist.destroy_process_group()
-            except Exception:   # noqa: BLE001
-                pass
-            raise RuntimeError(f'gradient exchange failed in slice callback: {err!r}') from err
+            how = abort_process_group()
+            raise GradientExchangeError(f'gradient exchange failed in slice callback: {err!r} (process group {how})') from err
         for w in self._works:
             w.wait()              # nccl: the current stream waits for the collective (no host block)
         cur.wait_stream(self.comm)
@@ -109,10 +158,18 @@ def broadcast_buffers(net, src=0):
     dist.broadcast(net.bn_buffers, src)
 
 
-def allreduce_gradients(net, world=None, average=True):
+def allreduce_gradients(net, world=None, average=True, wire_dtype='fp32'):
     """Sum (and average) the flat gradient arena across ranks in one collective."""
     g = net.arena.grad if net.arena.grad is not None else net._grad_arena
-    w = _all_reduce_sum(g)
+    if wire_dtype == 'bf16':
+        h = g.to(torch.bfloat16)
+        w = _all_reduce_sum(h)
+        if w is not None:
+            w.wait()
+        g.copy_(h)
+        w = None
+    else:
+        w = _all_reduce_sum(g)
     if w is not None:
         w.wait()
     if average:

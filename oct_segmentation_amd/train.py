@@ -66,7 +66,8 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
     exchange = None
     if world > 1:
         parallel.broadcast_parameters(net)
-        exchange = parallel.GradientExchange(net, nslices=int(cfg.get('allreduce_slices', 3)))
+        # cfg['allreduce_dtype'] = 'bf16': gradients cross xGMI as bfloat16 (half the bytes of the per-link-bound ring)
+        exchange = parallel.GradientExchange(net, nslices=int(cfg.get('allreduce_slices', 3)), wire_dtype=str(cfg.get('allreduce_dtype', 'fp32')))
     opt = model.configure_optimizers()
     history = []
     aug_rng = None
@@ -88,8 +89,11 @@ def fit(cfg, train_batches, val_batches=None, device='cuda', model_dir=None, aug
                 parallel.broadcast_buffers(net)
             # grad_scale = 1/W inside the backward + SUM all-reduce = DDP's gradient mean; the all-reduce runs slice by
             # slice beside the backward (parallel.GradientExchange)
-            loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
-                                                     grad_scale=1.0 / world, exchange=exchange)
+            try:
+                loss, logits, stats = net.train_step_raw(img, mask, normalize=True, mean=model._mean, std=model._std,
+                                                         grad_scale=1.0 / world, exchange=exchange)
+            except parallel.GradientExchangeError as e:   # the group is aborted: only a fresh process is a clean state
+                parallel.exit_on_exchange_failure(e)
             opt.step()
             model.record_step('train', stats, loss)
         if n_train == 0:

@@ -139,7 +139,7 @@ def test_gradients_kinkfree_fp32(cuda, cfg):
     err = (lg - logits_ref).abs().max().item()
     cos, worst_g, name = _grad_report(net.named_grads(), ref)
     print(f'{cfg} kink-free: logits max|d|={err:.3e} (scale {scale:.3e}); grad cosine {cos:.8f} worst per-param err {worst_g:.3e} ({name})')
-    assert err <= 2e-4 * max(1.0, scale)
+    assert err <= 1e-4 * max(1.0, scale)          # north_star's bound: kink-free runs measure 1e-6..5e-5 whatever the depth
     assert abs(loss.item() - loss_ref.item()) <= 1e-5
     assert cos >= 0.999999
     assert worst_g < 2e-3
@@ -371,11 +371,11 @@ def test_parity_at_larger_frames_fp32(cuda, arch, enc, S, B):
     err = (logits.cpu() - z.detach()).abs().max().item()
     cos, worst, name = _grad_report(net.named_grads(), ref)
     print(f'{arch}/{enc} {S}x{S}: logits max|d| {err:.2e} (scale {scale:.1f}), grad cosine {cos:.9f}, worst {worst:.2e} ({name})')
-    assert err <= 2e-4 * max(1.0, scale)
+    assert err <= 1e-4 * max(1.0, scale)          # north_star's 1e-4 (kink-free: measured 5e-6..2e-5 of the scale at 704 x 704)
     assert abs(loss.item() - loss_ref.item()) <= 1e-5
     assert cos >= 0.999999
     if S < 704:
         assert worst < 2e-3
     else:   # half a million pixels per frame: fp32 sums of that length (biases, split-K weight gradients) are judged against float64
         from test_gpu_deeplab import judge_gradients
-        judge_gradients(ref, net.named_grads(), img, mask, tag=f'{arch}/{enc} {S}: ', normalize=False)
+        judge_gradients(ref, net.named_grads(), img, mask, tag=f'{arch}/{enc} {S}: ', normalize=False, max_rejudged=4)

@@ -112,6 +112,23 @@ def _rank_main(rank, world, port, q):
         g0 = garena.clone()
         dist.broadcast(g0, 0)
         same_grads = bool(torch.equal(garena, g0))       # after the exchange EVERY rank holds the same averaged gradients
+        # the same step with the gradients on the wire as bfloat16: cast per slice on the comm stream, bf16 SUM,
+        # written back to the fp32 arena -- against the fp32 exchange: cosine >= 0.9999, Dice unchanged (the forward is the same)
+        bn_keep = net.bn_buffers.clone()
+        ex16 = P.GradientExchange(net, nslices=3, wire_dtype='bf16')
+        loss16, _, _ = net.train_step_raw(img[lo:hi].to(dev), mask[lo:hi].to(dev), normalize=True, mean=MEAN, std=STD,
+                                          grad_scale=1.0 / world, exchange=ex16)
+        torch.cuda.synchronize()
+        g16 = net._grad_arena.cpu()
+        cos16 = float(torch.nn.functional.cosine_similarity(g16.double(), garena.double(), dim=0))
+        rel16 = float((g16 - garena).abs().max() / garena.abs().max())
+        g16o = g16.clone()
+        dist.broadcast(g16o, 0)
+        assert cos16 >= 0.9999 and rel16 <= 2.0 ** -7 and abs(loss16.item() - loss.item()) <= 1e-3, (cos16, rel16)
+        assert torch.equal(g16, g16o), 'bf16 exchange: ranks disagree'
+        assert len(ex16.fired) == 3
+        net._grad_arena.copy_(garena.to(dev))
+        net.bn_buffers.copy_(bn_keep)
         opt = FusedOptimizer(net, 'Adam', 1e-3, 1e-4)
         opt.step()
         torch.cuda.synchronize()
@@ -166,7 +183,7 @@ def test_two_ranks_one_gpu_real_process_group(cuda):
 
 _RCCL_WORLD1 = r'''
 import json, os, sys
-ROOT = sys.argv[1]; port = int(sys.argv[2])
+ROOT = sys.argv[1]; port = int(sys.argv[2]); mode = sys.argv[3] if len(sys.argv) > 3 else 'ok'
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import torch.distributed as dist
@@ -205,8 +222,38 @@ try:
     FusedOptimizer(net, 'Adam', 1e-3, 0.0).step()
     torch.cuda.synchronize()
     out['stepped'] = bool(not torch.equal(before, net.arena.data) and torch.isfinite(net.arena.data).all())
+    # gradients on the wire as bfloat16 through RCCL (ncclBfloat16 SUM): one rank = a round trip through bf16 rounding
+    net2 = SegNet('unet', 'resnet18', classes=2, device=dev, compute_dtype=torch.float32, seed=5).train()
+    ex16 = P.GradientExchange(net2, nslices=3, wire_dtype='bf16')
+    net2.train_step_raw(img, mask, grad_scale=1.0, exchange=ex16)
+    torch.cuda.synchronize()
+    g16 = net2._grad_arena
+    out['bf16_cos'] = float(torch.nn.functional.cosine_similarity(g16.double(), g0.double(), dim=0))
+    out['bf16_roundtrip'] = bool(torch.equal(g16, g0.to(torch.bfloat16).float()))
+    out['bf16_fired'] = len(ex16.fired)
+    if mode == 'fail':
+        # a collective that raises inside a slice callback: the step must surface GradientExchangeError with the communicator ABORTED
+        # (not destroy_process_group, which can block on peers), and the driver's handler must leave with its non-zero code
+        real = P._all_reduce_sum
+        calls = []
+        def boom(t):
+            calls.append(1)
+            if len(calls) == 2:
+                raise RuntimeError('injected collective failure')
+            return real(t)
+        P._all_reduce_sum = boom
+        try:
+            net.train_step_raw(img, mask, grad_scale=1.0, exchange=ex)
+            out['raised'] = False
+        except P.GradientExchangeError as e:
+            out['raised'] = True
+            out['message'] = str(e)
+            out['group_alive'] = bool(dist.is_initialized())
+            print('RESULT ' + json.dumps(out), flush=True)
+            P.exit_on_exchange_failure(e, code=13)
 finally:
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 print('RESULT ' + json.dumps(out), flush=True)
 '''
 
@@ -230,3 +277,20 @@ def test_rccl_branch_world_size_one(cuda):
     fired = out['fired']
     assert sorted(k for k, _, _ in fired) == [0, 1, 2] and [k for k, _, _ in fired] == [2, 1, 0], fired
     assert fired[-1][1] == 0 and fired[0][2] == out['numel']
+    assert out['bf16_fired'] == 3 and out['bf16_roundtrip'] and out['bf16_cos'] >= 0.9999, out
+
+
+@pytest.mark.timeout(600)
+def test_failed_collective_aborts_the_group_and_exits_nonzero(cuda):
+    """a collective that fails inside a slice callback must not leave the rank continuing in-process on a half-reduced
+    gradient arena, and must not call destroy_process_group (which flushes outstanding work and can block on the peers): the RCCL
+    communicator is aborted (torch's _abort_process_group -> ncclCommAbort), GradientExchangeError surfaces, and the driver's handler
+    (parallel.exit_on_exchange_failure, what fit() and bench.py install) leaves with exit code 13."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_WORLD1, ROOT, str(_free_port()), 'fail'], capture_output=True, text=True, timeout=540, env=env)
+    assert r.returncode == 13, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][-1][len('RESULT '):])
+    assert out['raised'] and 'injected collective failure' in out['message'] and 'aborted' in out['message'], out
+    assert 'exiting with code 13' in r.stderr

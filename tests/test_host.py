@@ -209,7 +209,7 @@ def test_metrics_csv_bookkeeping(tmp_path):
 def test_planner_and_executors_clean_under_asan_ubsan():
     """SURVEY section 5 (sanitizers): the host halves of every source -- csrc/plan.cpp's graph builder, workspace layout, tap tables, launch
     geometry, job tables, and the forward / backward / sliced-backward / optimizer / graph executors -- compiled with
-    -fsanitize=address,undefined and driven over all 20 arch x encoder pairs (U-Net, U-Net++, LinkNet, FPN) (32x32, 16 x 704x704, 96x64, 64x160; f32 / bf16 / f16)
+    -fsanitize=address,undefined and driven over every arch x encoder pair the engine builds (32x32, 16 x 704x704, 96x64, 64x160; f32 / bf16 / f16: the plan count asserted below)
     against a recording stand-in for the HIP runtime (tools/hip_host_stubs.cpp: every launch geometry and every memset / copy range is
     checked; nothing runs on a GPU).  `make asan` builds build/asan/plan_dryrun; exit code 0 and the summary line = clean."""
     import subprocess

@@ -56,6 +56,11 @@ def _worker(rank, world, port, out):
         net._grad_arena.copy_(local_grad)
         P.allreduce_gradients(net, world, average=True)
         assert torch.allclose(net._grad_arena, expect, atol=1e-6)
+        # gradients on the wire as bfloat16: against the fp32 exchange cosine >= 0.9999, error <= 2^-7 of the largest
+        net._grad_arena.copy_(local_grad)
+        P.allreduce_gradients(net, world, average=True, wire_dtype='bf16')
+        cos = torch.nn.functional.cosine_similarity(net._grad_arena.double(), expect.double(), dim=0).item()
+        assert cos >= 0.9999 and (net._grad_arena - expect).abs().max().item() <= 2.0 ** -7 * expect.abs().max().item() * world, cos
         net.bn_buffers.add_(rank + 1.0)
         P.broadcast_buffers(net)
         assert torch.equal(net.bn_buffers, ref0.bn_buffers + 1.0)
