@@ -86,7 +86,7 @@ def test_deeplabv3_every_gradient_kinkfree_fp32(cuda, enc, classes, B, H, W):
     assert err <= 1e-4 * max(1.0, z.abs().max().item())
     assert abs(loss.item() - loss_ref.item()) <= 1e-5
     assert cos >= 0.999999
-    judge_gradients(ref, grads, img, mask, max_rejudged=20)
+    judge_gradients(ref, grads, img, mask, max_rejudged=6)
 
 
 def test_deeplabv3_eval_bf16_and_704(cuda):

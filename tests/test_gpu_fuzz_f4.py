@@ -48,7 +48,7 @@ def test_fuzz_f4_fp32(cuda, case):
     if arch == 'fpn':     # (FPN's own frames: test_gpu_fpn._pair does not rescale them, judge_gradients needs the frame the oracle saw)
         assert worst < 2e-3 or test_gpu_deeplab.judge_gradients(ref, grads, img, mask, tag=f'k={k} ') <= 2
     else:
-        test_gpu_deeplab.judge_gradients(ref, grads, img, mask, tag=f'k={k} ', max_rejudged=20)
+        test_gpu_deeplab.judge_gradients(ref, grads, img, mask, tag=f'k={k} ', max_rejudged=8)
 
 
 @pytest.mark.parametrize('arch,enc,B,classes,S', [('fpn', 'resnet50', 2, 1, 256), ('deeplabv3plus', 'resnet50', 3, 2, 256), ('pspnet', 'resnet50', 2, 1, 256),
@@ -57,7 +57,7 @@ def test_fuzz_f4_fp32(cuda, case):
 def test_f4_bf16_engine_vs_fp32_oracle(cuda, arch, enc, B, classes, S):
     """the sweep architectures in bf16 had property tests and one Dice check only.  Same criterion as the BASELINE nets
     (test_gpu_configs.test_bf16_engine_vs_fp32_oracle_bottleneck_256): bf16 engine against the fp32 oracle on kink-free nets at >= 256^2 --
-    Dice within 1e-3 (north_star), gradient cosine >= 0.999, logits within 3 % of their scale."""
+    Dice within 1e-3 (north_star), gradient cosine >= 0.9995, logits within 2 % of their scale."""
     from test_gpu_net import _grad_report
     import test_gpu_deeplab, test_gpu_deeplabv3, test_gpu_fpn, test_gpu_pspnet
     pair = {'fpn': test_gpu_fpn._pair, 'deeplabv3plus': test_gpu_deeplab._pair, 'pspnet': test_gpu_pspnet._pair, 'deeplabv3': test_gpu_deeplabv3._pair}[arch]
@@ -68,5 +68,5 @@ def test_f4_bf16_engine_vs_fp32_oracle(cuda, arch, enc, B, classes, S):
     cos, worst, name = test_gpu_pspnet._report(grads, ref) if arch == 'pspnet' else _grad_report(grads, ref)
     print(f'{arch}/{enc} bf16 {S}^2: logits {err:.2e}/{scale:.2f} ({err / max(scale, 1):.2%}), Dice loss {loss.item():.6f} vs {loss_ref.item():.6f}, grad cosine {cos:.6f}')
     assert abs(loss.item() - loss_ref.item()) <= 1e-3
-    assert cos >= 0.999
-    assert err <= 3e-2 * max(1.0, scale)
+    assert cos >= 0.9995                           # (measured 0.99964 .. 0.999999)
+    assert err <= 2e-2 * max(1.0, scale)           # (measured 0.35 % .. 1.2 % of the scale)
