@@ -59,6 +59,10 @@ hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+// wgrad1x1.hip: stride-1 1x1 weight gradients (bf16, 64-divisible channel counts, flattened pixel list) as an LDS-DMA ring pipeline;
+// launch_wgrad routes eligible launches there after flatten_1x1
+bool wgrad1x1_eligible(const WgradArgs& flattened, int dtype);
+hipError_t launch_wgrad1x1(int dtype, const WgradArgs& flattened, hipStream_t st);
 
 // elementwise.hip -----------------------------------------------------------------------------
 // BatchNorm finalize (training): reduce the [rows][C][2] slab -> mean/var, scale/shift, running stats.

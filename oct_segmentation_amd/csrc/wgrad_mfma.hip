@@ -514,6 +514,7 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a0, hipStream_t st) {
   if (thin_wgrad_eligible(a0, dtype)) return launch_thin_wgrad(dtype, a0, st);
   WgradArgs a = a0;
   flatten_1x1(a);
+  if (wgrad1x1_eligible(a, dtype)) return launch_wgrad1x1(dtype, a, st);
   if (a.ntaps == 1 || a.ntaps == 4 || a.ntaps == 9) {
     if (dtype == DT_F32) {
       if (a.ntaps == 1) return launch_wgrad_t<float, 1>(a, dtype, st);

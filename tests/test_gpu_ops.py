@@ -58,6 +58,11 @@ CASES = [
     (4, 1, 1, 2048, 256, 1, 1, 0, False),
     (2, 16, 24, 304, 256, 1, 1, 0, False),
     (2, 16, 24, 256, 48, 1, 1, 0, False),
+    # the LDS-DMA ring weight gradient (wgrad1x1.hip, bf16; >= 1024 pixels, 64-divisible channels): 1200 pixels = 18.75 stages of 64 (a
+    # three-k-step tail), three ci tiles, the 64-channel wave tile; and the 128-channel tile on two dy planes with split-K ranges of 4 stages
+    (3, 20, 20, 192, 64, 1, 1, 0, False),
+    (2, 32, 32, 64, 128, 1, 1, 0, False),
+    (1, 64, 80, 128, 384, 1, 1, 0, False),
 ]
 
 
