@@ -255,8 +255,6 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
         // fillers in the MFMA gaps (the wave is alone on its SIMD: a separate issue / store phase idles the pipe).
         constexpr int TH8 = 8, NSLOT = TH8 * NTAPS, NITEM = MAXY + MAXW;
         const int tile_bytes = (npy + npw) * PSTEP * PITCH;
-        struct Pair { s16x4_t lo, hi; };
-        struct Frags { uint4 y; uint4 x[NTAPS]; };
         TilePos tp2{0, 0, 0};
         const char* yb2 = nullptr;
         int gy02 = 0, gx02 = 0;
@@ -282,40 +280,52 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           if constexpr (J0 + 1 < J1 && J0 + 1 < NITEM) item(std::integral_constant<int, J0 + 1>{}, std::integral_constant<int, PH>{}, oy, ox);
           if constexpr (J0 + 2 < J1 && J0 + 2 < NITEM) item(std::integral_constant<int, J0 + 2>{}, std::integral_constant<int, PH>{}, oy, ox);
         };
-        auto load_y1 = [&](const char* by, int kk, Frags& f) __attribute__((always_inline)) {
-          const char* yrow = by + kk * TW * PITCH + ya0;
-          Pair ya;
-          ya.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow));
-          ya.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(yrow + 4 * PITCH));
-          f.y = __builtin_bit_cast(uint4, ya);
+        // WINDOW-ROW-major contraction (round 4).  Tap (r, s) of output row kk reads window row kk + r at column shift s, so the x fragment
+        // of (window row w, shift s) serves tap (0, s) of row w, tap (1, s) of row w - 1 and tap (2, s) of row w - 2: read ONCE per tile
+        // and used for three MFMAs (against three rotating dy fragments) instead of being re-read per tap -- 30 x + 8 dy fragments per
+        // tile instead of 72 + 8, 1.05 transposed reads per MFMA instead of 2.2 (counters of round 3's loop, profiles/
+        // r4_sq_counters_wgrad9_*.txt: 2.4 LDS + 4 vector + 1.3 scalar instructions per MFMA on a wave that is alone on its SIMD, 48 % of
+        // the cycles in the MFMA pipe).  Window row w carries 3 / 6 / 9 MFMAs (rows 0 and 9 / 1 and 8 / 2..7): 72 per tile as before,
+        // the same slot numbering for the staging fillers, fragments of window row w + 1 requested in the gaps of row w.
+        struct Frag { s16x4_t lo, hi; };
+        Frag xs[2][3], ys[4];
+        auto rd_x = [&](const char* xbase, auto wc, auto sc, auto hc) __attribute__((always_inline)) {
+          constexpr int Wn = decltype(wc)::value, S_ = decltype(sc)::value, H_ = decltype(hc)::value;
+          constexpr int OFF = (Wn * 18 + S_) * PITCH + H_ * 4 * PITCH;
+          if constexpr (H_ == 0) xs[Wn & 1][S_].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
+          else xs[Wn & 1][S_].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
         };
-        // this path is only taken for the standard 3x3 stride-1 tap table (host-checked): window rows are 18 pixels and
-        // tap t sits (t / 3) rows and (t % 3) pixels in, so every fragment address is one per-tile base register plus
-        // an immediate offset -- no address arithmetic in the MFMA gaps (the wave is alone on its SIMD: every
-        // instruction beside the MFMAs costs issue cycles nobody hides)
-        auto load_x1 = [&](const char* xbase, auto knc, auto tc, Frags& f) __attribute__((always_inline)) {
-          constexpr int KNR = decltype(knc)::value, t = decltype(tc)::value;
-          constexpr int OFF = ((KNR + t / 3) * 18 + t % 3) * PITCH;
-          Pair xb;
-          xb.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
-          xb.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF + 4 * PITCH));
-          f.x[t] = __builtin_bit_cast(uint4, xb);
+        auto rd_y = [&](const char* ybase, auto kc, auto hc) __attribute__((always_inline)) {
+          constexpr int Kn = decltype(kc)::value, H_ = decltype(hc)::value;
+          constexpr int OFF = Kn * TW * PITCH + H_ * 4 * PITCH;
+          if constexpr (H_ == 0) ys[Kn & 3].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ybase + OFF));
+          else ys[Kn & 3].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ybase + OFF));
         };
-        // the filler of slot KK*NTAPS + t sits behind MFMA t of row KK: expanded per row with constant indices
-        auto row_f = [&](auto kc, const Frags& cur, Frags& nxt, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
-          constexpr int KK = decltype(kc)::value;
-          constexpr int KN = KK + 1 < TH8 ? KK + 1 : TH8 - 1;
+        // read q of the prefetch list of window row Wn: x (shift 0, 1, 2) x (lo, hi), then dy (lo, hi)
+        auto prefetch = [&](auto wc, auto qc, const char* xbase, const char* ybase) __attribute__((always_inline)) {
+          constexpr int Wn = decltype(wc)::value, Q = decltype(qc)::value;
+          if constexpr (Q < 6) rd_x(xbase, wc, std::integral_constant<int, Q / 2>{}, std::integral_constant<int, Q % 2>{});
+          else rd_y(ybase, wc, std::integral_constant<int, Q - 6>{});
+        };
+        auto wrow = [&](auto wc, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
+          constexpr int Wr = decltype(wc)::value;                     // window row 0 .. 9
+          constexpr int KLO = Wr - 2 < 0 ? 0 : Wr - 2, KHI = Wr < TH8 ? Wr : TH8 - 1;
+          constexpr int CNT = (KHI - KLO + 1) * 3;                    // MFMAs of this window row
+          constexpr int S0 = Wr == 0 ? 0 : Wr == 1 ? 3 : Wr <= 8 ? 9 * (Wr - 1) : 69;   // slots before it: 3, 6, then 9 per row, 6, 3
+          constexpr int NR = Wr + 1 > TH8 + 1 ? 0 : (Wr + 1 < TH8 ? 8 : 6);           // reads for window row Wr + 1 (dy rows end at 7)
           const char* xbase = bx + xa0;
-          auto one = [&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (t < NTAPS) {
-              Tr<T>::mma(cur.y, cur.x[t], acc[t]);
+          const char* ybase = by + ya0;
+          auto one = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < CNT) {
+              constexpr int kk = KLO + j / 3, sft = j % 3, t = (Wr - kk) * 3 + sft;
+              Tr<T>::mma(__builtin_bit_cast(uint4, ys[kk & 3]), __builtin_bit_cast(uint4, xs[Wr & 1][sft]), acc[t]);
               __builtin_amdgcn_sched_barrier(0);
-              if constexpr (KK + 1 < TH8) {
-                if constexpr (t == 0) load_y1(by, KN, nxt);
-                load_x1(xbase, std::integral_constant<int, KN>{}, tc, nxt);
-              }
-              fillers(std::integral_constant<int, KK * NTAPS + t>{}, oy, ox);
+              constexpr int R0 = j * NR / CNT, R1 = (j + 1) * NR / CNT;
+              if constexpr (R0 < R1) prefetch(std::integral_constant<int, Wr + 1>{}, std::integral_constant<int, R0>{}, xbase, ybase);
+              if constexpr (R0 + 1 < R1) prefetch(std::integral_constant<int, Wr + 1>{}, std::integral_constant<int, R0 + 1>{}, xbase, ybase);
+              if constexpr (R0 + 2 < R1) prefetch(std::integral_constant<int, Wr + 1>{}, std::integral_constant<int, R0 + 2>{}, xbase, ybase);
+              fillers(std::integral_constant<int, S0 + j>{}, oy, ox);
               __builtin_amdgcn_sched_barrier(0);
             }
           };
@@ -338,30 +348,27 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           const char* bx = by + npy * PSTEP * PITCH;
           char* oy = smem + (cur ^ 1) * tile_bytes;
           char* ox = oy + npy * PSTEP * PITCH;
-          Frags fa, fb;
           {
-            const char* xbase = bx + xa0;
             auto z = std::integral_constant<int, 0>{};
-            load_y1(by, 0, fa);
-            load_x1(xbase, z, std::integral_constant<int, 0>{}, fa); load_x1(xbase, z, std::integral_constant<int, 1>{}, fa);
-            load_x1(xbase, z, std::integral_constant<int, 2>{}, fa);
-            if constexpr (NTAPS == 9) {
-              load_x1(xbase, z, std::integral_constant<int, 3>{}, fa); load_x1(xbase, z, std::integral_constant<int, 4>{}, fa);
-              load_x1(xbase, z, std::integral_constant<int, 5>{}, fa); load_x1(xbase, z, std::integral_constant<int, 6>{}, fa);
-              load_x1(xbase, z, std::integral_constant<int, 7>{}, fa); load_x1(xbase, z, std::integral_constant<int, 8>{}, fa);
-            }
+            auto o = std::integral_constant<int, 1>{};
+            rd_y(by + ya0, z, z); rd_y(by + ya0, z, o);
+            rd_x(bx + xa0, z, z, z); rd_x(bx + xa0, z, z, o);
+            rd_x(bx + xa0, z, o, z); rd_x(bx + xa0, z, o, o);
+            rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, z); rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, o);
           }
-          // loads of tile k+2 address the image through sg: bind it once the stores of tile k+1 (which only need
-          // scale / shift) are past -- the first load item sits in the second half of the tile
-          row_f(std::integral_constant<int, 0>{}, fa, fb, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 1>{}, fb, fa, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 2>{}, fa, fb, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 3>{}, fb, fa, by, bx, oy, ox);
+          // loads of tile k+2 address the image through sg: bind it once the stores of tile k+1 (which only need scale / shift) are
+          // past -- the first load item sits in the second half of the tile (slot 36 = the first MFMA of window row 5)
+          wrow(std::integral_constant<int, 0>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 1>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 2>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 3>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 4>{}, by, bx, oy, ox);
           sg.bind_image(tp2.n);
-          row_f(std::integral_constant<int, 4>{}, fa, fb, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 5>{}, fb, fa, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 6>{}, fa, fb, by, bx, oy, ox);
-          row_f(std::integral_constant<int, 7>{}, fb, fa, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 5>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 6>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 7>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 8>{}, by, bx, oy, ox);
+          wrow(std::integral_constant<int, 9>{}, by, bx, oy, ox);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
           cur ^= 1;
