@@ -574,7 +574,7 @@ hipError_t launch_mosaic(int dtype, const void* src, void* dst, int N, int H, in
 // BatchNorm partial sums of a plain NHWC tensor: slab[row][c] = (sum y, sum y^2) over the pixels row, row + rows, ... (the rows of
 // bn_finalize_train; for tensors whose producer is not a conv epilogue).  C / VEC <= 256 channel vectors.
 template <typename T>
-__global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t npix, int vpc, int C, float* slab) {
+__global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t npix, int vpc, int C, float* slab, int vstride, int cv0) {
   constexpr int VEC = EV<T>::VEC;
   __shared__ float red[256][2 * VEC + 1];
   const int tpv = 256 / vpc;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t
   if (pl < tpv)
     for (size_t p = (size_t)blockIdx.x * tpv + pl; p < npix; p += (size_t)gridDim.x * tpv) {
       float f[VEC];
-      EV<T>::unpack(ldv<T>(y, p * vpc + cv), f);
+      EV<T>::unpack(ldv<T>(y, p * vstride + cv0 + cv), f);     // (a chunk of vpc <= 256 channel vectors of a tensor with vstride per pixel)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { s1[i] += f[i]; s2[i] = fmaf(f[i], f[i], s2[i]); }
     }
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t
     for (int k = 1; k < tpv; ++k)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { s1[i] += red[threadIdx.x + k * vpc][i]; s2[i] += red[threadIdx.x + k * vpc][VEC + i]; }
-    float* o = slab + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+    float* o = slab + ((size_t)blockIdx.x * C + (cv0 + cv) * VEC) * 2;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { o[2 * i] = s1[i]; o[2 * i + 1] = s2[i]; }
   }
@@ -604,9 +604,13 @@ __global__ __launch_bounds__(256) void tensor_stats_kernel(const void* y, size_t
 hipError_t launch_tensor_stats(int dtype, const void* y, size_t npix, int C, float* slab, int rows, hipStream_t st) {
   OCTSEG_NO_F16(dtype);
   const int vec = dtype == DT_F32 ? 4 : 8;
-  if (C % vec != 0 || C / vec > 256 || rows < 1) return hipErrorInvalidValue;
-  if (dtype == DT_F32) hipLaunchKernelGGL(tensor_stats_kernel<float>, dim3(rows), dim3(256), 0, st, y, npix, C / vec, C, slab);
-  else hipLaunchKernelGGL(tensor_stats_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, y, npix, C / vec, C, slab);
+  if (C % vec != 0 || rows < 1) return hipErrorInvalidValue;
+  const int vtot = C / vec;
+  for (int cv0 = 0; cv0 < vtot; cv0 += 256) {      // wide tensors (RegNet stage 4: 1624 / 2240 channels) in chunks of 256 channel vectors
+    const int vpc = vtot - cv0 < 256 ? vtot - cv0 : 256;
+    if (dtype == DT_F32) hipLaunchKernelGGL(tensor_stats_kernel<float>, dim3(rows), dim3(256), 0, st, y, npix, vpc, C, slab, vtot, cv0);
+    else hipLaunchKernelGGL(tensor_stats_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, y, npix, vpc, C, slab, vtot, cv0);
+  }
   return hipGetLastError();
 }
 

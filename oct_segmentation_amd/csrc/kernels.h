@@ -136,9 +136,9 @@ hipError_t launch_maxpool_fwd(int dtype, const void* in, void* out, unsigned cha
                               int N, int H, int W, int C, hipStream_t st);
 hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const void* gout, void* gin, int N, int H, int W, int C, int store,
                                   hipStream_t st);
-// stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the 7x7 s2 p3 conv
+// stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the k x k stride-2 pad-(k / 2) conv (k = 7 ResNet, 3 RegNet)
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
-                              const float* mean, const float* stdv, int normalize, hipStream_t st);
+                              const float* mean, const float* stdv, int normalize, hipStream_t st, int ksize = 7);
 
 // Dice loss (multilabel, from logits) and / or mean binary cross-entropy with logits + confusion counts, logits/target NCHW f32
 constexpr int DICE_NS = 4;                                   // doubles per (image, class): I, S, T, BCE sum
@@ -203,7 +203,7 @@ hipError_t launch_drop_elem(int dtype, const void* in, const float* keep, float 
 hipError_t launch_bilinear_up(int dtype, const void* in, void* out, int N, int H, int W, int C, int up, hipStream_t st);                         // NHWC, align_corners=True
 // ---- DeepLabV3 (deeplab.hip): dense dilated convs as plain 3x3 convs on a mosaic of the rate^2 sub-grids
 hipError_t launch_mosaic(int dtype, const void* src, void* dst, int N, int H, int W, int C, int r, int to_mosaic, int accum, hipStream_t st);      // fine [N][H][W][C] <-> mosaic [N][r (hs + 1) + 1][r (ws + 1) + 1][C]
-hipError_t launch_tensor_stats(int dtype, const void* y, size_t npix, int C, float* slab, int rows, hipStream_t st);                            // slab [rows][C][2] = (sum, sum of squares)
+hipError_t launch_tensor_stats(int dtype, const void* y, size_t npix, int C, float* slab, int rows, hipStream_t st);   // (any C: channel chunks of <= 256 vectors)                            // slab [rows][C][2] = (sum, sum of squares)
 // ---- PSPNet (deeplab.hip)
 hipError_t launch_bin_mean(int dtype, const void* in, void* out, int N, int H, int W, int C, int k, hipStream_t st);                              // AdaptiveAvgPool2d((k, k)): out [N][k][k][C]
 hipError_t launch_bin_mean_bwd(int dtype, const void* gout, void* gin, int N, int H, int W, int C, int k, int accum, hipStream_t st);

@@ -255,11 +255,12 @@ struct Builder {
     int Cin = 0;
     const TensorInfo& t0 = P->tensors[srcs[0].v.t];
     L.N = t0.N; L.IH = t0.H << srcs[0].up; L.IW = t0.W << srcs[0].up;
-    for (auto& s : srcs) Cin += P->tensors[s.v.t].C;
+    for (auto& s : srcs) Cin += s.cn ? s.cn : P->tensors[s.v.t].C;
     L.Cin = Cin;
+    L.stem_k = P->stem_k;
     if (transposed) { L.OH = L.IH * 2; L.OW = L.IW * 2; }
     else { L.OH = (L.IH + 2 * pad - R) / stride + 1; L.OW = (L.IW + 2 * pad - R) / stride + 1; }
-    if (stem) L.w = param(name + ".weight", OCTSEG_P_STEM, 7, 7, Cout, 3, Cin);
+    if (stem) L.w = param(name + ".weight", OCTSEG_P_STEM, P->stem_k, P->stem_k, Cout, 3, Cin);
     else L.w = param(name + ".weight", transposed ? OCTSEG_P_CONVT : OCTSEG_P_CONV, R, R, Cout, Cin, 0);
     L.b = bias ? param(name + ".bias", OCTSEG_P_VEC, 1, 1, Cout, 1, 0) : -1;
     L.OP = (Cout + 15) / 16 * 16;
@@ -272,7 +273,7 @@ struct Builder {
     P->ops.push_back(op);
     const double taps = (double)R * R;
     // MACs: every output pixel of a plain conv sees R*S*Cin; ConvT k4 s2 sees 4 taps per output pixel
-    P->fwd_macs += (double)L.N * L.OH * L.OW * Cout * (stem ? 147.0 : (double)Cin * (transposed ? 4.0 : taps));
+    P->fwd_macs += (double)L.N * L.OH * L.OW * Cout * (stem ? 3.0 * P->stem_k * P->stem_k : (double)Cin * (transposed ? 4.0 : taps));
     Value v; v.t = L.out; v.bn = -1;
     if (!bn_name.empty()) {
       const int b = bn(bn_name, Cout, L.out, bn_lazy);
@@ -283,6 +284,27 @@ struct Builder {
       }
       v.bn = b;
     }
+    return v;
+  }
+  // Grouped k x k conv (timm RegNet's conv2: groups = width / group width) + BatchNorm: G independent convs, each reading a channel
+  // slice of `in` and writing a channel slice of ONE output tensor through the ordinary conv kernels (slices are pointer offsets: the
+  // descriptors carry the channel stride separately).  The parameter of group g is named <name>.weight#g<g>: the host mirror joins the
+  // groups along dim 0 into torch's [Cout][gw][k][k] tensor.  The BatchNorm's statistics come from the whole tensor (OP_STATS).
+  Value gconv(const std::string& name, Value in, int C, int R, int stride, int pad, int gw, const std::string& bn_name) {
+    const TensorInfo ti = P->tensors[in.t];
+    const int OH = (ti.H + 2 * pad - R) / stride + 1, OW = (ti.W + 2 * pad - R) / stride + 1;
+    const int out = tensor(ti.N, OH, OW, C);
+    for (int g = 0; g < C / gw; ++g) {
+      ConvSrc sc; sc.v = in; sc.up = 0; sc.c0 = g * gw; sc.cn = gw;
+      conv(name, {sc}, gw, R, stride, pad, "", false, false, false, false, true, out);
+      ConvLayer& L = P->convs.back();
+      L.accum_out = false; L.sliced = true; L.out_c0 = g * gw;
+      P->params[L.w].name = name + ".weight#g" + std::to_string(g);
+    }
+    const int bi = bn(bn_name, C, out, true);
+    for (auto& L : P->convs) if (L.sliced && L.out == out) L.fold_bn = bi;
+    stats_fin(bi, out);
+    Value v; v.t = out; v.bn = bi;
     return v;
   }
   // out = relu?(bn(y) + res) + post, materialised
@@ -501,6 +523,54 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 =
   return feats;  // f1 (S/2) .. f5 (S/32)
 }
 
+// timm RegNet as smp's RegNetEncoder wraps it (oracle/nets.py RegNetEncoder; reference configs/tune.yaml:19-24: timm-regnetx_002 /
+// timm-regnetx_064): stem 3x3 s2 -> 32 + BN + ReLU (im2col rows of 27 values padded to 32, then the GEMM the ResNet stem uses in f32),
+// four stages of bottleneck blocks -- conv1 1x1, conv2 GROUPED 3x3 (stride 2 in a stage's first block), conv3 1x1 without activation,
+// 1x1 stride-s conv shortcut where the shape changes, ReLU behind the sum.  Widths / depths / group width: timm generate_regnet.
+struct RegNetCfg { int w[4], d[4], gw; };
+static bool regnet_cfg(const std::string& enc, RegNetCfg& c) {
+  if (enc == "timm-regnetx_002") { c = RegNetCfg{{24, 56, 152, 368}, {1, 1, 4, 7}, 8}; return true; }
+  if (enc == "timm-regnetx_064") { c = RegNetCfg{{168, 392, 784, 1624}, {2, 4, 10, 1}, 56}; return true; }
+  return false;
+}
+std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
+  octseg_plan* P = b.P;
+  P->stem_k = 3;
+  const int KP = 32;   // 3 * 3 * 3 = 27 padded
+  P->col_tensor = b.tensor(P->B, P->H / 2, P->W / 2, KP, false);
+  { Op op; op.kind = OP_STEM_COL; op.out = P->col_tensor; P->ops.push_back(op); }
+  Value ystem = b.conv("encoder.stem.conv", {{mat(P->col_tensor), 0}}, 32, 1, 1, 0, "encoder.stem.bn", false, false, false, true);
+  std::vector<int> feats;
+  int x = b.bn_act(ystem, Value(), -1, true);
+  feats.push_back(x);
+  int prev = 32;
+  for (int si = 0; si < 4; ++si) {
+    const int w = cfg.w[si];
+    for (int bi = 0; bi < cfg.d[si]; ++bi) {
+      const int stride = bi == 0 ? 2 : 1;
+      const std::string pre = "encoder.s" + std::to_string(si + 1) + ".b" + std::to_string(bi + 1);
+      if (si + 2 > depth) {   // (smp encoder_depth 3: the stage keeps its parameters and buffers, no op)
+        b.dead_conv(pre + ".conv1.conv", w, prev, 1); b.dead_bn(pre + ".conv1.bn", w, x);
+        for (int g = 0; g < w / cfg.gw; ++g) { b.dead_conv(pre + ".conv2.conv", cfg.gw, cfg.gw, 3); P->params.back().name = pre + ".conv2.conv.weight#g" + std::to_string(g); }
+        b.dead_bn(pre + ".conv2.bn", w, x);
+        b.dead_conv(pre + ".conv3.conv", w, w, 1); b.dead_bn(pre + ".conv3.bn", w, x);
+        if (prev != w || stride != 1) { b.dead_conv(pre + ".downsample.conv", w, prev, 1); b.dead_bn(pre + ".downsample.bn", w, x); }
+        prev = w;
+        continue;
+      }
+      Value v1 = b.conv(pre + ".conv1.conv", {{mat(x), 0}}, w, 1, 1, 0, pre + ".conv1.bn", false);
+      Value v2 = b.gconv(pre + ".conv2.conv", v1, w, 3, stride, 1, cfg.gw, pre + ".conv2.bn");
+      Value v3 = b.conv(pre + ".conv3.conv", {{v2, 0}}, w, 1, 1, 0, pre + ".conv3.bn", false);
+      Value res = mat(x);
+      if (prev != w || stride != 1) res = b.conv(pre + ".downsample.conv", {{mat(x), 0}}, w, 1, stride, 0, pre + ".downsample.bn", false);
+      x = b.bn_act(v3, res, -1, true);
+      prev = w;
+    }
+    if (si + 2 <= depth) feats.push_back(x);
+  }
+  return feats;
+}
+
 Value unet_block(Builder& b, const std::string& pre, Value x, const std::vector<Value>& skips, int cout) {
   std::vector<ConvSrc> srcs;
   srcs.push_back({x, 1});
@@ -588,7 +658,18 @@ static void assign_lanes(octseg_plan* P) {
 static int build_plan(octseg_plan* P) {
   Builder b{P, dtype_size(P->dtype)};
   const bool dlv3 = P->arch == "deeplabv3";
-  std::vector<int> f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus" || dlv3, P->arch == "pspnet" ? 3 : 5, dlv3);  // f[0]=f1 .. f[4]=f5
+  std::vector<int> f;
+  RegNetCfg rcfg;
+  const bool regnet = regnet_cfg(P->encoder, rcfg);
+  if (regnet) {
+    if (P->arch == "deeplabv3plus" || dlv3) return fail(OCTSEG_UNSUPPORTED_ARCH, "the dilated RegNet encoders (smp make_dilated) are not built");
+    if (P->arch == "linknet" || P->arch == "pspnet")   // LinkNet's decoder blocks and PSPNet's pyramid branches run on a QUARTER of a feature's channels
+      return fail(OCTSEG_UNSUPPORTED_ARCH, P->arch + " over " + P->encoder + ": its decoder narrows a feature to a quarter of its channels (" +
+                  std::to_string(rcfg.w[P->arch == "pspnet" ? 1 : 3]) + " / 4 is not a multiple of the 8-channel vector the NHWC kernels move)");
+    f = build_regnet(b, rcfg, P->arch == "pspnet" ? 3 : 5);
+  } else {
+    f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus" || dlv3, P->arch == "pspnet" ? 3 : 5, dlv3);  // f[0]=f1 .. f[4]=f5
+  }
   while (f.size() < 5) f.push_back(f.back());       // (PSPNet: three features; the slots of the others are never read)
   std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
   std::vector<int> ench;
@@ -762,7 +843,7 @@ static int build_plan(octseg_plan* P) {
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
+  if (!regnet && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -820,7 +901,7 @@ static int build_plan(octseg_plan* P) {
       L.pk_dgrad = conv_pack_info(d0, P->dtype);
       L.wimg_dgrad_off = off; off += align_up(conv_image_bytes(L.pk_dgrad, wtaps));
     }
-    if (L.bn >= 0 && L.stem && thin_stem_eligible(P->dtype)) {
+    if (L.bn >= 0 && L.stem && (P->stem_k == 7 && thin_stem_eligible(P->dtype))) {
       P->bns[L.bn].rows = thin_stem_rows(L.N, P->H, P->W);   // the stem runs in thin.hip straight from the frame: one slab row per workgroup
       slab = std::max(slab, (size_t)P->bns[L.bn].rows * L.Cout * 2 * sizeof(float));
     } else if (L.bn >= 0) {
@@ -833,7 +914,7 @@ static int build_plan(octseg_plan* P) {
         int c0 = 0;
         for (auto& s : L.srcs) {
           SrcDesc d{}; d.H = P->tensors[s.v.t].H; d.W = P->tensors[s.v.t].W; d.up = s.up; d.C = P->tensors[s.v.t].C; d.c0 = c0;
-          c0 += d.C; a.src[a.nsrc++] = d;
+          c0 += s.cn ? s.cn : d.C; a.src[a.nsrc++] = d;
         }
         DstDesc dd{}; dd.H = L.OH; dd.W = L.OW; dd.C = L.Cout; dd.cn = L.Cout; a.dst[0] = dd; a.ndst = 1;
         a.bias = L.b >= 0 ? (const float*)(uintptr_t)16 : nullptr;   // presence only
@@ -848,6 +929,8 @@ static int build_plan(octseg_plan* P) {
     for (auto& s : L.srcs)
       if (s.up) tmp = std::max(tmp, (size_t)L.N * L.IH * L.IW * P->tensors[s.v.t].C * esz);
   }
+  for (auto& bn : P->bns)   // a BatchNorm behind a grouped conv: no conv epilogue feeds it, OP_STATS writes `rows` partial sums of the whole tensor
+    if (bn.rows == 0) bn.rows = 512;
   // one-launch weight packing: job table + prefix sums (uploaded into the workspace on first use)
   P->pack_jobs.clear(); P->pack_prefix.clear(); P->pack_total = 0;
   for (auto& L : P->convs) {
@@ -856,7 +939,7 @@ static int build_plan(octseg_plan* P) {
       if (tr == 1 && !L.has_dgrad) continue;
       const ConvPackInfo& pk = tr ? L.pk_dgrad : L.pk_fwd;
       PackJob j{P->params[L.w].off, tr ? L.wimg_dgrad_off : L.wimg_fwd_off, taps, L.Cout, L.Cin, tr, pk.BN, pk.RB, pk.nchunks, pk.ntiles,
-                (!tr && L.bn >= 0) ? P->bns[L.bn].ss_off : ~(size_t)0};
+                (!tr && L.bn >= 0) ? P->bns[L.bn].ss_off : (!tr && L.fold_bn >= 0) ? P->bns[L.fold_bn].ss_off + (size_t)L.out_c0 * sizeof(float) : ~(size_t)0};
       P->pack_prefix.push_back(P->pack_total);
       P->pack_jobs.push_back(j);
       P->pack_total += (unsigned long long)taps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
@@ -941,12 +1024,12 @@ struct Exec {
     for (auto& s : L.srcs) {
       const TensorInfo& t = P->tensors[s.v.t];
       SrcDesc d;
-      d.ptr = act(s.v.t);
-      d.scale = s.v.bn >= 0 ? bn_scale(s.v.bn) : nullptr;
-      d.shift = s.v.bn >= 0 ? bn_shift(s.v.bn) : nullptr;
+      d.ptr = (char*)act(s.v.t) + (size_t)s.c0 * dtype_size(P->dtype);          // (channel slice of a grouped conv: pointer offset,
+      d.scale = s.v.bn >= 0 ? bn_scale(s.v.bn) + s.c0 : nullptr;                 //  the channel stride stays the tensor's)
+      d.shift = s.v.bn >= 0 ? bn_shift(s.v.bn) + s.c0 : nullptr;
       d.C = t.C; d.c0 = c0; d.H = t.H; d.W = t.W; d.up = s.up; d.relu = s.v.bn >= 0 ? 1 : 0;
       src[n++] = d;
-      c0 += t.C;
+      c0 += s.cn ? s.cn : t.C;
     }
     return n;
   }
@@ -956,7 +1039,7 @@ struct Exec {
 
 // algorithmic multiply-accumulates of one pass (forward = dgrad = wgrad) over a conv layer
 static double layer_macs(const ConvLayer& L) {
-  return (double)L.N * L.OH * L.OW * L.Cout * (L.stem ? 147.0 : (double)L.Cin * (L.transposed ? 4.0 : (double)L.R * L.S));
+  return (double)L.N * L.OH * L.OW * L.Cout * (L.stem ? 3.0 * L.stem_k * L.stem_k : (double)L.Cin * (L.transposed ? 4.0 : (double)L.R * L.S));
 }
 
 // fold = 1 (eval forwards): scale / shift of every BatchNorm from the running statistics first (one launch), then every forward
@@ -1049,15 +1132,15 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       case OP_STEM_COL: {
         const TensorInfo& t = P->tensors[op.out];
         // (2-byte dtypes: the stem conv gathers its im2col rows straight from the frame in LDS, thin.hip KSTEM -- no 634 MB tensor)
-        if (!thin_stem_eligible(P->dtype))
-          HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st));
+        if (!(P->stem_k == 7 && thin_stem_eligible(P->dtype)))
+          HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st, P->stem_k));
         tseq[op.out] = stamp;
         break;
       }
       case OP_CONV: {
         const ConvLayer& L = P->convs[op.conv];
         for (auto& sct : L.srcs) { rc = need_val(lane, sct.v); if (rc) return rc; }
-        if (L.stem && thin_stem_eligible(P->dtype)) {
+        if (L.stem && (P->stem_k == 7 && thin_stem_eligible(P->dtype))) {
           StemArgs sa;
           memset(&sa, 0, sizeof(sa));
           sa.img = image; sa.N = P->B; sa.H = P->H; sa.W = P->W; sa.normalize = normalize;
@@ -1084,10 +1167,14 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           a.nsrc = E.fill_srcs(L, a.src);
           a.W = fwd_weight(E, L);
           a.bias = L.b >= 0 ? E.params + P->params[L.b].off : nullptr;
-          if (!L.stem) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0; }   // (ConvT: [4][4][O][I], same indexing)
+          // (ConvT: [4][4][O][I], same indexing; the stem's im2col GEMM: [O][KP] = one tap of KP input channels)
+          a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 0;
           if (folded) {
             for (int i = 0; i < a.nsrc; ++i) { a.src[i].scale = nullptr; a.src[i].shift = nullptr; a.src[i].relu = 0; }
             if (L.bn >= 0) { a.bias = E.bn_shift(L.bn); a.relu_out = P->bns[L.bn].lazy ? 1 : 0; a.wscale = E.bn_scale(L.bn); }
+            else if (L.fold_bn >= 0) {   // one group of a grouped conv: its slice of the tensor's BatchNorm
+              a.bias = E.bn_shift(L.fold_bn) + L.out_c0; a.relu_out = P->bns[L.fold_bn].lazy ? 1 : 0; a.wscale = E.bn_scale(L.fold_bn) + L.out_c0;
+            }
           }
           a.ndst = 1;
           DstDesc d;
@@ -1096,7 +1183,10 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
             d.ptr = P->head_up > 1 ? (void*)(E.ws + P->z4_off) : (void*)logits;
             d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_HEAD_NCHW;
           }
-          else { d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE; }
+          else {
+            d.ptr = (char*)E.act(L.out) + (size_t)L.out_c0 * dtype_size(P->dtype);
+            d.C = L.sliced ? P->tensors[L.out].C : L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; a.out_mode = OUT_STORE;
+          }
           a.dst[0] = d;
           a.stat_slab = (L.bn >= 0 && E.train) ? slab_l : nullptr;
           a.slab_row0 = row0;
@@ -1323,7 +1413,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   octseg_plan* P = E.P;
   const size_t esz = dtype_size(P->dtype);
   const Geom g = E.geom(L);
-  if (L.stem && thin_stem_eligible(P->dtype)) {
+  if (L.stem && (P->stem_k == 7 && thin_stem_eligible(P->dtype))) {
     // the forward built no im2col tensor.  Weight gradient straight from the frame (thin.hip); the deterministic-reduction mode keeps the
     // atomics-free kernel and rebuilds the im2col rows for it here.  The frame needs no gradient.
     if (P->stem_image == nullptr) return fail(OCTSEG_BAD_ARG, "backward without a training forward of this plan (stem frame unknown)");
@@ -1384,8 +1474,10 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   for (size_t i = 0; i < L.srcs.size(); ++i) {
     const int ti = L.srcs[i].v.t;
     const TensorInfo& t = P->tensors[ti];
+    const int scn = L.srcs[i].cn ? L.srcs[i].cn : t.C;      // channels of this source inside the layer's input (a slice for grouped convs)
+    const size_t soff = (size_t)L.srcs[i].c0 * esz;
     DstDesc d;
-    d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = 0; d.pool = 0;
+    d.C = t.C; d.c0 = c0; d.cn = scn; d.H = L.IH; d.W = L.IW; d.accum = 0; d.pool = 0;
     static const bool no_fuse_pool = getenv("OCTSEG_NO_FUSED_POOL") != nullptr;
     if (L.srcs[i].up && t.need_grad && !no_fuse_pool && ld.size() == 1 && ld[0].ostride == 1 && (L.IH % 2) == 0 && (L.IW % 2) == 0) {
       // gradient of the nearest-x2 upsample: the dgrad epilogue sums the 2x2 quads straight into the source's gradient
@@ -1396,6 +1488,12 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       up_src = (int)i;
     } else if (!t.need_grad) {
       d.ptr = E.ws + P->tmp_off; d.accum = 0;   // never happens for multi-source convs; keeps the descriptor valid
+    } else if (L.srcs[i].cn) {
+      // one group of a grouped conv: it owns a channel slice of the source's gradient.  The first group to arrive zeroes the whole
+      // tensor, every group then accumulates into its slice (first-writer stores are per tensor, not per slice)
+      if (!E.ginit[ti]) { HIPCHK(hipMemsetAsync(E.grad(ti), 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st)); E.ginit[ti] = 1; }
+      d.ptr = (char*)E.grad(ti) + soff;
+      d.accum = 1;
     } else {
       d.ptr = E.grad(ti);
       d.accum = E.claim(ti);
@@ -1405,13 +1503,13 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       }
     }
     dst[nd++] = d;
-    c0 += t.C;
+    c0 += scn;
   }
   for (auto& a : ld) {
     SrcDesc s;
     s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1;
-    a.Cin = dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero
+    a.Cin = L.sliced ? L.Cout : dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero (a group: its own channels, dyC is the stride)
     a.W = E.ws + L.wimg_dgrad_off;
     if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 1; }
     for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
@@ -1519,6 +1617,7 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
       case OP_CONV: {
         const ConvLayer& L = P->convs[op.conv];
         if (L.head) rc = conv_backward(E, L, E.ws + (P->head_up > 1 ? P->dz4_off : P->dlogits_off), P->dlogits_C);
+        else if (L.sliced) rc = conv_backward(E, L, (char*)E.grad(L.out) + (size_t)L.out_c0 * dtype_size(P->dtype), P->tensors[L.out].C);
         else rc = conv_backward(E, L, E.grad(L.out), L.Cout);
         if (rc) return rc;
         break;
@@ -1713,8 +1812,9 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   }
   if (d->batch <= 0 || d->classes <= 0 || d->classes > 16) return fail(OCTSEG_BAD_SHAPE, "batch > 0 and 1 <= classes <= 16 required");
   const std::string enc = lower(d->encoder);
-  if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101" && enc != "resnet152")
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152)");
+  if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101" && enc != "resnet152" && enc != "timm-regnetx_002" &&
+      enc != "timm-regnetx_064")
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152 | timm-regnetx_002 | timm-regnetx_064)");
   octseg_plan* P = new octseg_plan();
   P->arch = lower(d->arch); P->encoder = enc; P->classes = d->classes;
   P->B = d->batch; P->H = d->height; P->W = d->width; P->dtype = d->dtype;

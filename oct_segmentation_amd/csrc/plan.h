@@ -50,7 +50,7 @@ struct GNInfo {
   size_t part_off, ss_off, stat_off, coef_off;   // workspace byte offsets: partial sums, scale/shift [N][C][2], mean/rstd and backward means [N][G][2]
 };
 
-struct ConvSrc { Value v; int up; };
+struct ConvSrc { Value v; int up; int c0 = 0, cn = 0; };   // c0 / cn: channel slice [c0, c0 + cn) of the tensor (cn = 0: all of it) -- grouped convs
 
 struct ConvLayer {
   std::string name;
@@ -67,6 +67,11 @@ struct ConvLayer {
   bool has_dgrad;
   int OP;                   // channel count of dy as the dgrad sees it (Cout rounded up to 16)
   bool accum_out = false;   // the forward ADDS into an existing tensor (FPNBlock: nearest-x2 fill, then the skip conv accumulates)
+  int out_c0 = 0;           // first channel of `out` this layer writes, and (sliced) whether it owns only a channel slice of it: one group of a
+  bool sliced = false;      // grouped conv (RegNet's conv2: groups = width / group width) -- G independent convs on channel slices
+  int stem_k = 7;           // stem layers: kernel size of the im2col rows (7: torchvision ResNet, 3: timm RegNet)
+  int fold_bn = -1;         // sliced layers: the BatchNorm of the whole tensor (not fed by this layer's epilogue in training); eval forwards
+                            // fold its scale / shift for channels [out_c0, out_c0 + Cout) into this group's image and epilogue
 };
 
 enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
@@ -137,6 +142,7 @@ struct octseg_plan {
   int loss_kind = 0;                         // LOSS_DICE | LOSS_BCE | LOSS_DICE_BCE (octseg_plan_set_loss)
   size_t dice_off = 0;                       // double sums[1 + B][C][DICE_NS]: totals, then one replica per image
   int col_tensor = -1;
+  int stem_k = 7;                            // kernel size of the stem conv (7x7 s2 p3 ResNet, 3x3 s2 p1 RegNet): rows of OP_STEM_COL
   int dlogits_C = 16;
   double fwd_macs = 0;
   // side stream of the backward: weight gradients only depend on dy and on saved activations, so they run

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
         };
         // read q of the prefetch list of window row Wn: x (shift 0, 1, 2) x (lo, hi), then dy (lo, hi)
         auto prefetch = [&](auto wc, auto qc, const char* xbase, const char* ybase) __attribute__((always_inline)) {
-          constexpr int Wn = decltype(wc)::value, Q = decltype(qc)::value;
+          constexpr int Q = decltype(qc)::value;
           if constexpr (Q < 6) rd_x(xbase, wc, std::integral_constant<int, Q / 2>{}, std::integral_constant<int, Q % 2>{});
           else rd_y(ybase, wc, std::integral_constant<int, Q - 6>{});
         };

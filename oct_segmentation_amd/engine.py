@@ -20,11 +20,14 @@ _ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', '
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
-_ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152')
+_ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
+             # timm RegNet through smp's RegNetEncoder (reference configs/tune.yaml:19-24); grouped 3x3 convs run as per-group launches
+             'timm-regnetx_002', 'timm-regnetx_064')
 
 
 def get_preprocessing_params(encoder_name, pretrained='imagenet'):
-    """smp.encoders.get_preprocessing_params for the torchvision ResNets (model.py:49)."""
+    """smp.encoders.get_preprocessing_params (model.py:49): the torchvision ResNets and smp's timm-regnet* entries share the ImageNet
+    statistics below."""
     if encoder_name not in _ENCODERS:
         raise KeyError(f'Wrong encoder name `{encoder_name}`, supported encoders: {list(_ENCODERS)}')
     return {'input_space': 'RGB', 'input_range': [0, 1], 'mean': [0.485, 0.456, 0.406], 'std': [0.229, 0.224, 0.225]}
@@ -231,10 +234,15 @@ class SegNet(nn.Module):
         self.register_buffer('num_batches_tracked', torch.zeros((), dtype=torch.long))
         self._grad_arena = torch.zeros(self.param_numel, dtype=torch.float32, device=self.device)
         self._by_name = {p['name']: p for p in self.param_table}
+        # grouped convs (timm RegNet conv2): the engine holds one parameter per group, named <key>#g<k>; torch holds ONE tensor
+        # [Cout][gw][k][k] = the groups joined along dim 0.  _keyed: state_dict key -> the engine parameters behind it, in order
+        self._keyed = OrderedDict()
+        for p in self.param_table:
+            self._keyed.setdefault(p['name'].split('#g')[0], []).append(p)
         # element ranges of the arena that an optimizer may touch.  PSPNet (smp encoder_depth 3) keeps encoder.layer3 / layer4 in its
         # state_dict without ever running them: torch optimizers skip parameters whose gradient is None, so weight decay must not
         # reach them here either -- the fused optimizer steps over the live ranges only
-        dead = ('encoder.layer3.', 'encoder.layer4.') if a == 'pspnet' else ()
+        dead = (('encoder.s3.', 'encoder.s4.') if encoder_name.startswith('timm-regnet') else ('encoder.layer3.', 'encoder.layer4.')) if a == 'pspnet' else ()
         self._dead_prefixes = dead
         self.live_ranges, lo = [], 0
         for p in sorted(self.param_table, key=lambda q: q['offset']):
@@ -310,8 +318,8 @@ class SegNet(nn.Module):
             return flat.view(p['R'], p['S'], p['O'], p['I']).permute(2, 3, 0, 1)
         if p['kind'] == L.P_CONVT:
             return flat.view(p['R'], p['S'], p['O'], p['I']).permute(3, 2, 0, 1)
-        if p['kind'] == L.P_STEM:
-            return flat.view(p['O'], p['KP'])[:, :147].view(p['O'], 7, 7, 3).permute(0, 3, 1, 2)
+        if p['kind'] == L.P_STEM:      # [O][KP] im2col rows, k = (r * S + s) * 3 + ci (7x7: 147 of 160; timm RegNet's 3x3 stem: 27 of 32)
+            return flat.view(p['O'], p['KP'])[:, :p['R'] * p['S'] * 3].view(p['O'], p['R'], p['S'], 3).permute(0, 3, 1, 2)
         return flat
 
     def torch_shape(self, p):
@@ -336,6 +344,8 @@ class SegNet(nn.Module):
                             t.uniform_(-bound, bound, generator=g)
                     else:
                         t.fill_(1.0)
+                        if self.encoder_name.startswith('timm-regnet') and name.endswith('.conv3.bn.weight'):
+                            t.zero_()      # timm RegNet(zero_init_last=True): the block's last BatchNorm starts at gamma = 0
                 elif name.startswith('encoder.'):
                     nn.init.kaiming_normal_(t, mode='fan_out', nonlinearity='relu', generator=g)
                 elif name.startswith('segmentation_head.'):
@@ -355,8 +365,10 @@ class SegNet(nn.Module):
     def state_dict(self, destination=None, prefix='', keep_vars=False):
         sd = OrderedDict() if destination is None else destination
         bn_by_name = {b['name']: b for b in self.bn_table}
-        for p in self.param_table:
-            sd[prefix + p['name']] = self._torch_view(p).detach().clone().contiguous()
+        for key, parts in self._keyed.items():
+            p = parts[-1]
+            sd[prefix + key] = (self._torch_view(p).detach().clone().contiguous() if len(parts) == 1 else
+                                torch.cat([self._torch_view(q).detach() for q in parts], dim=0).contiguous())
             if p['name'].endswith('.bias') and p['name'][:-5] in bn_by_name:
                 b = bn_by_name[p['name'][:-5]]
                 base = prefix + b['name']
@@ -374,13 +386,17 @@ class SegNet(nn.Module):
             raise RuntimeError(f'Error(s) in loading state_dict for SegNet: missing keys {missing[:5]}..., '
                                f'unexpected keys {unexpected[:5]}...')
         with torch.no_grad():
-            for p in self.param_table:
-                if p['name'] in state_dict:
-                    src = state_dict[p['name']]
-                    view = self._torch_view(p)
-                    if tuple(src.shape) != tuple(view.shape):
-                        raise RuntimeError(f"size mismatch for {p['name']}: {tuple(src.shape)} vs {tuple(view.shape)}")
-                    view.copy_(src.to(self.device, torch.float32))
+            for key, parts in self._keyed.items():
+                if key in state_dict:
+                    src = state_dict[key]
+                    views = [self._torch_view(q) for q in parts]
+                    want = (sum(v.shape[0] for v in views),) + tuple(views[0].shape[1:])
+                    if tuple(src.shape) != want:
+                        raise RuntimeError(f"size mismatch for {key}: {tuple(src.shape)} vs {want}")
+                    o = 0
+                    for v in views:      # (one view for ordinary parameters; the groups of a grouped conv are slices along dim 0)
+                        v.copy_(src[o:o + v.shape[0]].to(self.device, torch.float32))
+                        o += v.shape[0]
             for b in self.bn_table:
                 for key, off in (('running_mean', b['mean_offset']), ('running_var', b['var_offset'])):
                     k = f"{b['name']}.{key}"
@@ -399,7 +415,8 @@ class SegNet(nn.Module):
     def named_grads(self):
         """Gradients of the last backward, per parameter, in torch layout (for parity tests)."""
         src = self.arena.grad if self.arena.grad is not None else self._grad_arena
-        return OrderedDict((p['name'], self._torch_view(p, src).detach().clone().contiguous()) for p in self.param_table)
+        return OrderedDict((key, torch.cat([self._torch_view(q, src).detach() for q in parts], dim=0).clone().contiguous())
+                           for key, parts in self._keyed.items())
 
     # ------------------------------------------------------------------ execution
     def _plan(self, B, H, W):

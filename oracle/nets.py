@@ -152,6 +152,124 @@ class ResNetEncoder(nn.Module):
         return feats
 
 
+
+# ------------------------------------------------------------------------------------------------ RegNet encoders
+# smp 0.3.3 ``encoders/timm_regnet.py`` (RegNetEncoder over timm==0.9.2 ``models/regnet.py``), the ``timm-regnetx_002`` /
+# ``timm-regnetx_064`` / ``timm-regnety_120`` rows of the reference's sweep (configs/tune.yaml:19-24).  Neither package is installed
+# here: restated from the published sources -- stage widths from timm's generate_regnet / adjust_widths_groups_comp, module tree and
+# attribute names (stem.conv / stem.bn, s{i}.b{j}.conv{1,2,3}.{conv,bn}, .se.fc{1,2}, .downsample.{conv,bn}) as timm's, so that
+# state_dict keys equal a reference checkpoint's.  Pinned by the published parameter counts (tests/test_oracle.py).
+_REGNET_CFG = {   # smp's _mcfg rows: w0, wa, wm, group_w, depth, se_ratio (bottle_ratio 1.0, stem_width 32)
+    'timm-regnetx_002': dict(w0=24, wa=36.44, wm=2.49, group_w=8, depth=13, se_ratio=0.0),
+    'timm-regnetx_064': dict(w0=184, wa=60.83, wm=2.07, group_w=56, depth=17, se_ratio=0.0),
+    'timm-regnety_120': dict(w0=168, wa=73.36, wm=2.37, group_w=112, depth=19, se_ratio=0.25),
+}
+
+
+def regnet_stages(cfg):
+    """(widths, depths, group widths) of the four stages: timm generate_regnet (quant 8) + adjust_widths_groups_comp (bottle_ratio 1)."""
+    import numpy as np
+    cont = np.arange(cfg['depth']) * cfg['wa'] + cfg['w0']
+    exps = np.round(np.log(cont / cfg['w0']) / np.log(cfg['wm']))
+    widths = (np.round(np.divide(cfg['w0'] * np.power(cfg['wm'], exps), 8)) * 8).astype(int).tolist()
+    stage_w, stage_d = [], []
+    for w in widths:
+        if stage_w and stage_w[-1] == w:
+            stage_d[-1] += 1
+        else:
+            stage_w.append(w); stage_d.append(1)
+    gs = [min(cfg['group_w'], w) for w in stage_w]
+    stage_w = [int(round(w / g) * g) for w, g in zip(stage_w, gs)]       # bottleneck width a multiple of the group width
+    return stage_w, stage_d, gs
+
+
+for _n, _c in _REGNET_CFG.items():
+    ENCODER_CHANNELS[_n] = (3, 32) + tuple(regnet_stages(_c)[0])
+
+
+class ConvNormAct(nn.Module):
+    """timm.layers.ConvNormAct: .conv (no bias) + .bn (BatchNormAct2d: BatchNorm2d with the activation fused behind it)."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        self.act = act
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x) if self.act else x
+
+
+class SEModule(nn.Module):
+    """timm.layers.SEModule: mean over (H, W) -> fc1 (1x1 conv, bias) -> ReLU -> fc2 -> sigmoid gate."""
+
+    def __init__(self, channels, rd_channels):
+        super().__init__()
+        self.fc1 = nn.Conv2d(channels, rd_channels, 1, bias=True)
+        self.fc2 = nn.Conv2d(rd_channels, channels, 1, bias=True)
+
+    def forward(self, x):
+        s = x.mean((2, 3), keepdim=True)
+        s = self.fc2(F.relu(self.fc1(s)))
+        return x * s.sigmoid()
+
+
+class RegNetBottleneck(nn.Module):
+    """timm regnet.Bottleneck (bottle_ratio 1): conv1 1x1, conv2 grouped 3x3 (stride), optional SE with in_chs * se_ratio reduction
+    channels, conv3 1x1 without activation, 1x1 conv shortcut where the shape changes, ReLU behind the sum."""
+
+    def __init__(self, cin, cout, stride, group_w, se_ratio):
+        super().__init__()
+        self.conv1 = ConvNormAct(cin, cout, 1)
+        self.conv2 = ConvNormAct(cout, cout, 3, stride, groups=cout // group_w)
+        self.se = SEModule(cout, int(round(cin * se_ratio))) if se_ratio else None
+        self.conv3 = ConvNormAct(cout, cout, 1, act=False)
+        self.downsample = ConvNormAct(cin, cout, 1, stride, act=False) if (cin != cout or stride != 1) else None
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        if self.se is not None:
+            y = self.se(y)
+        y = self.conv3(y)
+        return F.relu(y + (self.downsample(x) if self.downsample is not None else x))
+
+
+class RegNetEncoder(nn.Module):
+    """smp RegNetEncoder.get_stages: [identity, stem, s1, s2, s3, s4] (head deleted; final_conv is an Identity for these configs)."""
+
+    def __init__(self, name, in_channels=3, depth=5):
+        super().__init__()
+        cfg = _REGNET_CFG[name]
+        self._depth = depth
+        self.out_channels = ENCODER_CHANNELS[name][:depth + 1]
+        widths, depths, gs = regnet_stages(cfg)
+        self.stem = ConvNormAct(in_channels, 32, 3, 2)
+        prev = 32
+        for i, (w, d, g) in enumerate(zip(widths, depths, gs)):
+            stage = nn.Sequential()
+            for j in range(d):
+                stage.add_module(f'b{j + 1}', RegNetBottleneck(prev, w, 2 if j == 0 else 1, g, cfg['se_ratio']))
+                prev = w
+            self.add_module(f's{i + 1}', stage)
+        for m in self.modules():      # timm regnet._init_weights (zero_init_last=True: conv3.bn.weight = 0)
+            if isinstance(m, nn.Conv2d):
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+        for m in self.modules():
+            if isinstance(m, RegNetBottleneck):
+                nn.init.zeros_(m.conv3.bn.weight)
+
+    def forward(self, x):
+        feats = [x]
+        x = self.stem(x); feats.append(x)
+        for i in range(1, self._depth):
+            x = getattr(self, f's{i}')(x); feats.append(x)
+        return feats
+
+
 class Conv2dReLU(nn.Sequential):
     def __init__(self, cin, cout, kernel_size, padding=0):
         super().__init__(
@@ -543,7 +661,12 @@ def _init_head(module):
 class SegmentationModel(nn.Module):
     def __init__(self, arch, encoder_name, in_channels, classes):
         super().__init__()
-        self.encoder = ResNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)
+        if encoder_name in _REGNET_CFG:
+            if arch in ('deeplabv3', 'deeplabv3plus'):
+                raise ValueError('the dilated (make_dilated) RegNet encoders are not restated')
+            self.encoder = RegNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)
+        else:
+            self.encoder = ResNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)
         ch = self.encoder.out_channels
         if arch == 'unet':
             self.decoder = UnetDecoder(ch)

@@ -83,7 +83,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 
 int main() {
   const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3"};
-  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152"};
+  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
   unsigned long long checksum = 0;
@@ -93,6 +93,9 @@ int main() {
         for (int dtype = 0; dtype < 3; ++dtype)
           for (int classes : {1, 4}) {
             if (classes == 4 && !(sh[1] == 96 || dtype == 1)) continue;   // (the class count only changes the head: a subset is enough)
+            // timm RegNet encoders (grouped convs as per-group layers on channel slices): the engine builds them under U-Net, U-Net++ and
+            // FPN; LinkNet / PSPNet (quarter-width decoder convs: 92, 14 ... channels) and the dilated DeepLab encoders are refused (below)
+            if (!strncmp(enc, "timm-", 5) && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet") || !strncmp(arch, "deeplab", 7))) continue;
             octseg_net_desc d{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
             octseg_plan* p = nullptr;
             if (octseg_plan_create(&d, &p) != 0 || !p) {
@@ -143,6 +146,9 @@ int main() {
           }
   // shapes the builder must refuse (smp check_input_shape / argument checks) without touching memory it does not own
   octseg_plan* q = nullptr;
+  octseg_net_desc badr1{"linknet", "timm-regnetx_002", 1, 1, 32, 32, 0}, badr2{"deeplabv3plus", "timm-regnetx_064", 1, 2, 64, 64, 1},
+      badr3{"pspnet", "timm-regnetx_002", 1, 2, 64, 64, 0};
+  if (octseg_plan_create(&badr1, &q) == 0 || octseg_plan_create(&badr2, &q) == 0 || octseg_plan_create(&badr3, &q) == 0) { fprintf(stderr, "an unsupported RegNet pair was accepted\n"); return 7; }
   octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"manet", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
       bad4{"unet", "resnet18", 0, 1, 32, 32, 0}, bad5{"unet", "resnet18", 1, 1, 32, 32, 7};
   for (octseg_net_desc* b : {&bad1, &bad2, &bad3, &bad4, &bad5})
