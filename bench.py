@@ -47,6 +47,7 @@ WORKLOADS = {
     'deeplabv3_r50_704': ('deeplabv3', 'resnet50', 1, 704),
     'unet_regnetx064_704': ('unet', 'timm-regnetx_064', 1, 704),     # timm RegNet encoders of the sweep (configs/tune.yaml:19-24)
     'fpn_regnetx002_704': ('fpn', 'timm-regnetx_002', 1, 704),
+    'unet_regnety120_704': ('unet', 'timm-regnety_120', 1, 704),
 }
 
 

@@ -57,6 +57,12 @@ int thin_stem_rows(int N, int H, int W);
 hipError_t launch_thin_stem_forward(int dtype, const StemArgs& s, hipStream_t st);
 hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
+// se.hip: squeeze-excite gate of timm's SEModule (RegNetY): out (+)= in * sigmoid(s[n][c]) and the gate's own gradient
+// ds[n][c] = sigmoid'(s) * sum_p g * x (float scratch `part`: N x se_dgate_shares(HW) x C floats)
+hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st);
+int se_dgate_shares(int HW);
+hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* s, void* ds, float* part, int N, int HW, int C, hipStream_t st);
+
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 // wgrad1x1.hip: stride-1 1x1 weight gradients (bf16, 64-divisible channel counts, flattened pixel list) as an LDS-DMA ring pipeline;

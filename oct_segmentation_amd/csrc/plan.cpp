@@ -437,6 +437,19 @@ struct Builder {
     P->ops.push_back(op);
     return o;
   }
+  // timm SEModule(channels, rd_channels): x * sigmoid(fc2(relu(fc1(mean_hw(x))))), x = the materialised activation `in`
+  int se(const std::string& name, int in, int rd) {
+    const TensorInfo t = P->tensors[in];
+    const int g = gap(in);
+    const Value f1 = conv(name + ".fc1", {{mat_(g), 0}}, rd, 1, 1, 0, "", true);
+    const int r1 = relu(f1.t);
+    const Value f2 = conv(name + ".fc2", {{mat_(r1), 0}}, t.C, 1, 1, 0, "", true);
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_SEGATE; op.in = in; op.ins[0] = f2.t; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  static Value mat_(int t) { Value v; v.t = t; v.bn = -1; return v; }
   // parameters and buffers of a layer the graph never runs (smp's get_encoder(depth=3) keeps layer3 / layer4 in the module and in state_dict)
   void dead_conv(const std::string& name, int Cout, int Cin, int R) { param(name + ".weight", OCTSEG_P_CONV, R, R, Cout, Cin, 0); }
   void dead_bn(const std::string& name, int C, int any_tensor) { bn(name, C, any_tensor, false); }
@@ -527,10 +540,11 @@ std::vector<int> build_resnet(Builder& b, const std::string& enc, bool dilate4 =
 // timm-regnetx_064): stem 3x3 s2 -> 32 + BN + ReLU (im2col rows of 27 values padded to 32, then the GEMM the ResNet stem uses in f32),
 // four stages of bottleneck blocks -- conv1 1x1, conv2 GROUPED 3x3 (stride 2 in a stage's first block), conv3 1x1 without activation,
 // 1x1 stride-s conv shortcut where the shape changes, ReLU behind the sum.  Widths / depths / group width: timm generate_regnet.
-struct RegNetCfg { int w[4], d[4], gw; };
+struct RegNetCfg { int w[4], d[4], gw; bool se; };   // se: RegNetY -- SEModule behind conv2 with round(0.25 * block input channels) reduction channels
 static bool regnet_cfg(const std::string& enc, RegNetCfg& c) {
-  if (enc == "timm-regnetx_002") { c = RegNetCfg{{24, 56, 152, 368}, {1, 1, 4, 7}, 8}; return true; }
-  if (enc == "timm-regnetx_064") { c = RegNetCfg{{168, 392, 784, 1624}, {2, 4, 10, 1}, 56}; return true; }
+  if (enc == "timm-regnetx_002") { c = RegNetCfg{{24, 56, 152, 368}, {1, 1, 4, 7}, 8, false}; return true; }
+  if (enc == "timm-regnetx_064") { c = RegNetCfg{{168, 392, 784, 1624}, {2, 4, 10, 1}, 56, false}; return true; }
+  if (enc == "timm-regnety_120") { c = RegNetCfg{{224, 448, 896, 2240}, {2, 5, 11, 1}, 112, true}; return true; }
   return false;
 }
 std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
@@ -553,6 +567,11 @@ std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
         b.dead_conv(pre + ".conv1.conv", w, prev, 1); b.dead_bn(pre + ".conv1.bn", w, x);
         for (int g = 0; g < w / cfg.gw; ++g) { b.dead_conv(pre + ".conv2.conv", cfg.gw, cfg.gw, 3); P->params.back().name = pre + ".conv2.conv.weight#g" + std::to_string(g); }
         b.dead_bn(pre + ".conv2.bn", w, x);
+        if (cfg.se) {
+          const int rd = (int)lround(prev * 0.25);
+          b.dead_conv(pre + ".se.fc1", rd, w, 1); b.param(pre + ".se.fc1.bias", OCTSEG_P_VEC, 1, 1, rd, 1, 0);
+          b.dead_conv(pre + ".se.fc2", w, rd, 1); b.param(pre + ".se.fc2.bias", OCTSEG_P_VEC, 1, 1, w, 1, 0);
+        }
         b.dead_conv(pre + ".conv3.conv", w, w, 1); b.dead_bn(pre + ".conv3.bn", w, x);
         if (prev != w || stride != 1) { b.dead_conv(pre + ".downsample.conv", w, prev, 1); b.dead_bn(pre + ".downsample.bn", w, x); }
         prev = w;
@@ -560,6 +579,10 @@ std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
       }
       Value v1 = b.conv(pre + ".conv1.conv", {{mat(x), 0}}, w, 1, 1, 0, pre + ".conv1.bn", false);
       Value v2 = b.gconv(pre + ".conv2.conv", v1, w, 3, stride, 1, cfg.gw, pre + ".conv2.bn");
+      if (cfg.se) {   // RegNetY: the gate acts on relu(bn(conv2)), materialised for it
+        const int xa = b.bn_act(v2, Value(), -1, true);
+        v2 = mat(b.se(pre + ".se", xa, (int)lround(prev * 0.25)));
+      }
       Value v3 = b.conv(pre + ".conv3.conv", {{v2, 0}}, w, 1, 1, 0, pre + ".conv3.bn", false);
       Value res = mat(x);
       if (prev != w || stride != 1) res = b.conv(pre + ".downsample.conv", {{mat(x), 0}}, w, 1, stride, 0, pre + ".downsample.bn", false);
@@ -663,7 +686,7 @@ static int build_plan(octseg_plan* P) {
   const bool regnet = regnet_cfg(P->encoder, rcfg);
   if (regnet) {
     if (P->arch == "deeplabv3plus" || dlv3) return fail(OCTSEG_UNSUPPORTED_ARCH, "the dilated RegNet encoders (smp make_dilated) are not built");
-    if (P->arch == "linknet" || P->arch == "pspnet")   // LinkNet's decoder blocks and PSPNet's pyramid branches run on a QUARTER of a feature's channels
+    if ((P->arch == "linknet" && (rcfg.w[3] / 4) % 8 != 0) || (P->arch == "pspnet" && (rcfg.w[1] / 4) % 8 != 0))   // LinkNet's decoder blocks and PSPNet's pyramid branches run on a QUARTER of a feature's channels
       return fail(OCTSEG_UNSUPPORTED_ARCH, P->arch + " over " + P->encoder + ": its decoder narrows a feature to a quarter of its channels (" +
                   std::to_string(rcfg.w[P->arch == "pspnet" ? 1 : 3]) + " / 4 is not a multiple of the 8-channel vector the NHWC kernels move)");
     f = build_regnet(b, rcfg, P->arch == "pspnet" ? 3 : 5);
@@ -971,6 +994,12 @@ static int build_plan(octseg_plan* P) {
     P->pool_idx_off = off; off += align_up(pool_elems);   // one buffer: the ResNet stems have exactly one max-pool
   }
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
+  {
+    size_t se_part = 0;
+    for (auto& op : P->ops)
+      if (op.kind == OP_SEGATE) { const TensorInfo& t = P->tensors[op.in]; se_part = std::max(se_part, (size_t)t.N * se_dgate_shares(t.H * t.W) * t.C * sizeof(float)); }
+    P->se_part_off = off; off += align_up(se_part);
+  }
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * DICE_NS * sizeof(double));   // totals + per-image replicas
   P->ws_bytes = off;
@@ -1314,6 +1343,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
           const TensorInfo& t = P->tensors[op.in];
           HIPCHK(launch_tensor_stats(P->dtype, E.act(op.in), (size_t)t.N * t.H * t.W, b.C, slab_l, b.rows, st));
         }
+        break;
+      }
+      case OP_SEGATE: {
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_se_gate(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), t.N, t.H * t.W, t.C, 0, st));
         break;
       }
       case OP_RESIZE: {
@@ -1684,6 +1718,15 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         break;
       }
       case OP_STATS: break;
+      case OP_SEGATE: {     // d x (+)= g * sigmoid(s);  d s = sigmoid'(s) * sum_p g * x
+        const TensorInfo& t = P->tensors[op.in];
+        HIPCHK(launch_se_dgate(P->dtype, E.grad(op.out), E.act(op.in), E.act(op.ins[0]), E.grad(op.ins[0]), (float*)(E.ws + P->se_part_off), t.N, t.H * t.W,
+                               t.C, E.st));
+        E.ginit[op.ins[0]] = 1;
+        const int acc = E.claim(op.in);
+        HIPCHK(launch_se_gate(P->dtype, E.grad(op.out), E.act(op.ins[0]), E.grad(op.in), t.N, t.H * t.W, t.C, acc, E.st));
+        break;
+      }
       case OP_MOSAIC: {     // the inverse re-arrangement of the gradient (gutters of a mosaic gradient are zero)
         const TensorInfo& tf = P->tensors[op.oc0 ? op.in : op.out];
         const int acc = E.claim(op.in);
@@ -1813,8 +1856,8 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   if (d->batch <= 0 || d->classes <= 0 || d->classes > 16) return fail(OCTSEG_BAD_SHAPE, "batch > 0 and 1 <= classes <= 16 required");
   const std::string enc = lower(d->encoder);
   if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101" && enc != "resnet152" && enc != "timm-regnetx_002" &&
-      enc != "timm-regnetx_064")
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152 | timm-regnetx_002 | timm-regnetx_064)");
+      enc != "timm-regnetx_064" && enc != "timm-regnety_120")
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152 | timm-regnetx_002 | timm-regnetx_064 | timm-regnety_120)");
   octseg_plan* P = new octseg_plan();
   P->arch = lower(d->arch); P->encoder = enc; P->classes = d->classes;
   P->B = d->batch; P->H = d->height; P->W = d->width; P->dtype = d->dtype;

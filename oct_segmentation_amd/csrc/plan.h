@@ -93,7 +93,8 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               OP_DROP2D,     // out = in * Dropout2d keep pattern [N][C] / (1 - p)
               // DeepLabV3 (deeplab.hip)
               OP_MOSAIC,     // out = mosaic of the rate^2 sub-grids of in (oc0 = 1), or in's mosaic gathered back (oc0 = 0); rate = up
-              OP_STATS };    // BatchNorm partial sums of tensor `in` for BN `bn` (its producer is not a conv epilogue)
+              OP_STATS,      // BatchNorm partial sums of tensor `in` for BN `bn` (its producer is not a conv epilogue)
+              OP_SEGATE };   // out = in * sigmoid(ins[0] [N][1][1][C]): the squeeze-excite gate (timm SEModule, RegNetY; se.hip)
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -138,6 +139,7 @@ struct octseg_plan {
   size_t bwd_part_off = 0, bwd_cnt_off = 0;  // scratch / tickets of the BN-backward reduce kernel that finishes its own reduction
   size_t pool_idx_off = 0;                   // maxpool: window position of every maximum (1 byte per output element)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
+  size_t se_part_off = 0;                    // float scratch of the squeeze-excite gate's own gradient (se.hip)
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
   int loss_kind = 0;                         // LOSS_DICE | LOSS_BCE | LOSS_DICE_BCE (octseg_plan_set_loss)
   size_t dice_off = 0;                       // double sums[1 + B][C][DICE_NS]: totals, then one replica per image

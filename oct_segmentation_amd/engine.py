@@ -22,7 +22,7 @@ _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channel
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
 _ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
              # timm RegNet through smp's RegNetEncoder (reference configs/tune.yaml:19-24); grouped 3x3 convs run as per-group launches
-             'timm-regnetx_002', 'timm-regnetx_064')
+             'timm-regnetx_002', 'timm-regnetx_064', 'timm-regnety_120')   # (RegNetY: + squeeze-excite gates, csrc/se.hip)
 
 
 def get_preprocessing_params(encoder_name, pretrained='imagenet'):

@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
 # scale (regnetx_002) against 8e-7 on the same nets kink-free (cosine 1.00000000, every gradient within 5e-5): flips, not arithmetic.
 T.FWD_TOL.setdefault('timm-regnetx_002', 4e-4)
 T.FWD_TOL.setdefault('timm-regnetx_064', 2e-4)
+T.FWD_TOL.setdefault('timm-regnety_120', 2e-4)
 
 NETS = [('unet', 'timm-regnetx_002', 1, 2, 64), ('unetplusplus', 'timm-regnetx_002', 2, 3, 64), ('unet', 'timm-regnetx_064', 1, 2, 64),
-        ('unet', 'timm-regnetx_002', 2, 2, 96)]
+        ('unet', 'timm-regnetx_002', 2, 2, 96),
+        # RegNetY: squeeze-excite gates behind every grouped conv (mean -> fc1 -> ReLU -> fc2 -> sigmoid); LinkNet fits it (2240 / 4 = 560)
+        ('unet', 'timm-regnety_120', 1, 2, 64), ('linknet', 'timm-regnety_120', 2, 3, 64)]
 IDS = ['-'.join(map(str, c)) for c in NETS]
 
 
@@ -32,7 +35,7 @@ def test_regnet_gradients_kinkfree_fp32(cuda, cfg):
     T.test_gradients_kinkfree_fp32(cuda, cfg)
 
 
-@pytest.mark.parametrize('cfg', NETS[:3], ids=IDS[:3])
+@pytest.mark.parametrize('cfg', NETS[:3] + NETS[4:5], ids=IDS[:3] + IDS[4:5])
 def test_regnet_eval_forward_and_keys_fp32(cuda, cfg):
     from oct_segmentation_amd.engine import SegNet
     arch, enc, classes, B, S = cfg
@@ -78,7 +81,8 @@ def test_regnet_larger_frame_fp32(cuda):
         judge_gradients(ref, net.named_grads(), img, mask, tag='unet/regnetx_002 256x320: ', normalize=False, max_rejudged=4)
 
 
-@pytest.mark.parametrize('cfg', [('unet', 'timm-regnetx_002', 1, 2, 256), ('unetplusplus', 'timm-regnetx_064', 1, 2, 256)], ids=lambda c: '-'.join(map(str, c)))
+@pytest.mark.parametrize('cfg', [('unet', 'timm-regnetx_002', 1, 2, 256), ('unetplusplus', 'timm-regnetx_064', 1, 2, 256), ('unet', 'timm-regnety_120', 1, 2, 256)],
+                         ids=lambda c: '-'.join(map(str, c)))
 def test_regnet_bf16_engine_vs_fp32_oracle(cuda, cfg):
     from oracle import DiceLoss
     from oct_segmentation_amd.engine import SegNet

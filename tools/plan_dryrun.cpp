@@ -83,7 +83,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 
 int main() {
   const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3"};
-  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064"};
+  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064", "timm-regnety_120"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
   unsigned long long checksum = 0;
@@ -95,7 +95,7 @@ int main() {
             if (classes == 4 && !(sh[1] == 96 || dtype == 1)) continue;   // (the class count only changes the head: a subset is enough)
             // timm RegNet encoders (grouped convs as per-group layers on channel slices): the engine builds them under U-Net, U-Net++ and
             // FPN; LinkNet / PSPNet (quarter-width decoder convs: 92, 14 ... channels) and the dilated DeepLab encoders are refused (below)
-            if (!strncmp(enc, "timm-", 5) && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet") || !strncmp(arch, "deeplab", 7))) continue;
+            if (!strncmp(enc, "timm-", 5) && (!strncmp(arch, "deeplab", 7) || (strcmp(enc, "timm-regnety_120") && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet"))))) continue;
             octseg_net_desc d{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
             octseg_plan* p = nullptr;
             if (octseg_plan_create(&d, &p) != 0 || !p) {
