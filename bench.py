@@ -48,6 +48,8 @@ WORKLOADS = {
     'unet_regnetx064_704': ('unet', 'timm-regnetx_064', 1, 704),     # timm RegNet encoders of the sweep (configs/tune.yaml:19-24)
     'fpn_regnetx002_704': ('fpn', 'timm-regnetx_002', 1, 704),
     'unet_regnety120_704': ('unet', 'timm-regnety_120', 1, 704),
+    'unet_effb0_704': ('unet', 'efficientnet-b0', 1, 704),           # efficientnet_pytorch encoders of the sweep (configs/tune.yaml:25-28)
+    'fpn_effb5_704': ('fpn', 'efficientnet-b5', 1, 704),
 }
 
 

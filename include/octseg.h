@@ -8,6 +8,7 @@
  *                                      src/models/smp/model.py:38-44
  *   octseg_plan_set_dropout            the nn.Dropout2d inside smp's FPN decoder (arch "fpn") / the nn.Dropout of DeepLabV3+'s
  *                                      ASPP.project (arch "deeplabv3plus"): its keep pattern, injected
+ *   octseg_plan_set_drop_connect       efficientnet_pytorch's drop_connect on the id skips of MBConv blocks (encoders "efficientnet-b*")
  *   octseg_plan_param_info / bn_info   the nn.Module parameter / buffer tree behind state_dict()
  *                                      (load_from_checkpoint, src/predict.py:39-48)
  *   octseg_net_forward                 OCTSegmentationModel.forward (normalize=1, model.py:65-71) and
@@ -64,7 +65,8 @@ typedef enum { OCTSEG_F32 = 0, OCTSEG_BF16 = 1, OCTSEG_F16 = 2 } octseg_dtype;
 
 typedef struct {
   const char* arch;     /* "unet" | "unetplusplus" | "linknet" | "fpn" | "deeplabv3plus" | "deeplabv3" | "pspnet" (case-insensitive) */
-  const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" */
+  const char* encoder;  /* "resnet18" | "resnet34" | "resnet50" | "resnet101" | "resnet152" | "timm-regnetx_002" | "timm-regnetx_064" |
+                           "timm-regnety_120" | "efficientnet-b0" | "efficientnet-b5" | "efficientnet-b7" (smp encoder names) */
   int classes;          /* output channels */
   int batch, height, width;
   int dtype;            /* octseg_dtype: storage/MFMA input type of activations (accumulate is f32) */
@@ -135,6 +137,14 @@ int octseg_plan_params_changed(octseg_plan* plan);
  * device float [batch][512] of 0 / 1.  Its parameter table still lists encoder.layer3 / layer4 (smp keeps them in state_dict): they
  * never run and their gradients are zero. */
 int octseg_plan_set_dropout(octseg_plan* plan, const float* keep_dev);
+
+/* encoder "efficientnet-b0" | "-b5" | "-b7" (efficientnet_pytorch through smp's EfficientNetEncoder; reference sweep configs/tune.yaml:25-28):
+ * every MBConv block with an identity skip applies drop_connect in training -- x / (1 - rate) * floor(1 - rate + U[0, 1)) per sample, rate =
+ * 0.2 * block index / blocks.  The caller draws the decisions and hands over the FACTORS: device float [octseg_plan_num_drop_connect()][batch]
+ * of 0 or 1 / (1 - octseg_plan_drop_connect_rate(i)), caller-owned, read by the next training forward AND its backward.  Eval ignores it. */
+int octseg_plan_set_drop_connect(octseg_plan* plan, const float* factors_dev);
+int octseg_plan_num_drop_connect(const octseg_plan* plan);
+float octseg_plan_drop_connect_rate(const octseg_plan* plan, int index);
 
 /* Serving path (reference: src/models/smp/predict.py segment(), model.py:183-200 predict()): enable = 1 makes every
  * eval-mode octseg_net_forward of this plan run as a hipGraph -- the first call with a given argument set runs

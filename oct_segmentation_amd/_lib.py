@@ -88,6 +88,9 @@ SYMBOLS['octseg_net_train_step'] = (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P
                                               C.c_float, _P])
 SYMBOLS['octseg_plan_set_train_graph'] = (C.c_int, [_P, C.c_int])
 SYMBOLS['octseg_plan_set_loss'] = (C.c_int, [_P, C.c_int])
+SYMBOLS['octseg_plan_set_drop_connect'] = (C.c_int, [_P, _P])
+SYMBOLS['octseg_plan_num_drop_connect'] = (C.c_int, [_P])
+SYMBOLS['octseg_plan_drop_connect_rate'] = (C.c_float, [_P, C.c_int])
 LOSS_KINDS = {'dice': 0, 'bce': 1, 'dice+bce': 2}
 SLICE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t)
 SYMBOLS['octseg_net_backward_sliced'] = (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, C.c_int, _P, SLICE_CB, _P])

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_finalize_eval_all_kernel(const float* 
   }
   const BnEvalJob jb = tab[lo];
   const int c = (int)(g - prefix[lo]);
-  const float sc = params[jb.gamma_off + c] / sqrtf(buffers[jb.rv_off + c] + eps);
+  const float sc = params[jb.gamma_off + c] / sqrtf(buffers[jb.rv_off + c] + (jb.eps > 0.f ? jb.eps : eps));
   float* ss = (float*)(ws + jb.ss_off);
   ss[c] = sc;
   float sh = params[jb.beta_off + c] - buffers[jb.rm_off + c] * sc;
@@ -872,7 +872,7 @@ hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const voi
 // of the reference's forward() is fused here (raw 0..255 BGR input).
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, void* col, int N, int H, int W, int KP,
-                                                          float m0, float m1, float m2, float i0, float i1, float i2, int KS) {
+                                                          float m0, float m1, float m2, float i0, float i1, float i2, int KS, int PT) {
   constexpr int VEC = EV<T>::VEC;
   const int OH = H / 2, OW = W / 2, vpr = KP / VEC;
   const size_t nvec = (size_t)N * OH * OW * vpr;
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, void
       if (k < KS * KS * 3) {   // KS = 7: 147 of KP = 160; KS = 3 (timm RegNet stem): 27 of 32
         const int tap = k / 3, ci = k - tap * 3;
         const int r = tap / KS, s = tap - r * KS;
-        const int iy = 2 * oy - KS / 2 + r, ix = 2 * ox - KS / 2 + s;
+        const int iy = 2 * oy - PT + r, ix = 2 * ox - PT + s;     // (PT: 3 ResNet, 1 RegNet, 0 EfficientNet's static 'same' padding)
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)
           val = (img[(((size_t)n * 3 + ci) * H + iy) * W + ix] - mean[ci]) * inv[ci];
       }
@@ -901,17 +901,18 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* img, void
   }
 }
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
-                              const float* mean, const float* stdv, int normalize, hipStream_t st, int ksize) {
+                              const float* mean, const float* stdv, int normalize, hipStream_t st, int ksize, int pad) {
+  if (pad < 0) pad = ksize / 2;
   const size_t nvec = (size_t)N * (H / 2) * (W / 2) * (KP / (dtype == DT_F32 ? 4 : 8));
   const int gr = grid_for(nvec, 256);
   float m[3] = {0, 0, 0}, iv[3] = {1, 1, 1};
   if (normalize) for (int i = 0; i < 3; ++i) { m[i] = mean[i]; iv[i] = 1.0f / stdv[i]; }
   if (dtype == DT_F16)
-    hipLaunchKernelGGL(stem_im2col_kernel<f16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize);
+    hipLaunchKernelGGL(stem_im2col_kernel<f16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize, pad);
   else if (dtype == DT_F32)
-    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize);
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize, pad);
   else
-    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize);
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, img, col, N, H, W, KP, m[0], m[1], m[2], iv[0], iv[1], iv[2], ksize, pad);
   return hipGetLastError();
 }
 

@@ -57,6 +57,29 @@ int thin_stem_rows(int N, int H, int W);
 hipError_t launch_thin_stem_forward(int dtype, const StemArgs& s, hipStream_t st);
 hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
+// effnet.hip: the non-GEMM operators of efficientnet_pytorch's MBConvBlock (smp 'efficientnet-b0' / '-b5' / '-b7')
+struct DwgArgs {           // depthwise K x K (3 | 5), stride 1 | 2, top/left padding `pad` (TF static "same"); w / dw: fp32 [K][K][C]
+  const void* in; void* out; void* gin; const float* w; float* dw;   // backward: out = gout, gin = gradient of `in`
+  int N, H, W, C, OH, OW, K, stride, pad, accum;
+};
+hipError_t launch_dwg_fwd(int dtype, const DwgArgs& a, hipStream_t st);
+hipError_t launch_dwg_bwd_data(int dtype, const DwgArgs& a, hipStream_t st);
+hipError_t launch_dwg_bwd_w(int dtype, const DwgArgs& a, hipStream_t st);
+struct BnxArgs {           // forward: out = act(y * scale + shift) * dscale[n] + post;  backward: out = g(=post) * dscale[n] * act'(y * scale + shift)
+  const void* y; const float* scale; const float* shift; const float* dscale; const void* post; void* out;
+  size_t npix; int hw, C, act;    // act: 0 identity, 1 swish
+};
+hipError_t launch_bnx_fwd(int dtype, const BnxArgs& a, hipStream_t st);
+hipError_t launch_bnx_bwd(int dtype, const BnxArgs& a, hipStream_t st);
+struct SefcArgs {          // s = W2 swish(W1 m + b1) + b2 on pooled vectors m [N][C] (T); W1 [R][C], W2 [C][R] fp32; h / dh: float [N][R] scratch
+  const void* m; void* s; const void* ds; void* dm;
+  const float* w1; const float* b1; const float* w2; const float* b2; float* dw1; float* db1; float* dw2; float* db2;
+  float* h; float* dh;
+  int N, C, R;
+};
+hipError_t launch_sefc_fwd(int dtype, const SefcArgs& a, hipStream_t st);
+hipError_t launch_sefc_bwd(int dtype, const SefcArgs& a, hipStream_t st);   // dm, dh, then the four parameter gradients (accumulated)
+
 // se.hip: squeeze-excite gate of timm's SEModule (RegNetY): out (+)= in * sigmoid(s[n][c]) and the gate's own gradient
 // ds[n][c] = sigmoid'(s) * sum_p g * x (float scratch `part`: N x se_dgate_shares(HW) x C floats)
 hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st);
@@ -90,7 +113,8 @@ hipError_t launch_bn_finalize_eval(int C, const float* gamma, const float* beta,
 
 // eval: scale/shift of every BatchNorm of a plan in one launch (job table + channel prefix sums in the workspace)
 struct BnEvalJob { size_t gamma_off, beta_off, rm_off, rv_off /*floats*/, ss_off /*bytes*/; int C;
-                   size_t bias_off; /* floats: bias of the conv in front of this BN, folded into the shift (~0: none) */ };
+                   size_t bias_off; /* floats: bias of the conv in front of this BN, folded into the shift (~0: none) */
+                   float eps;       /* this BatchNorm's eps (> 0; 0: the launch's default -- 1e-5 torch, 1e-3 efficientnet_pytorch) */ };
 hipError_t launch_bn_finalize_eval_all(const float* params, const float* buffers, void* ws, const BnEvalJob* tab, const unsigned* prefix,
                                        int njobs, unsigned total, float eps, hipStream_t st);
 
@@ -144,7 +168,7 @@ hipError_t launch_maxpool_bwd_idx(int dtype, const unsigned char* idx, const voi
                                   hipStream_t st);
 // stem: NCHW f32 image -> (normalise) -> im2col rows [N, H/2, W/2, KP] T for the k x k stride-2 pad-(k / 2) conv (k = 7 ResNet, 3 RegNet)
 hipError_t launch_stem_im2col(int dtype, const float* img, void* col, int N, int H, int W, int KP,
-                              const float* mean, const float* stdv, int normalize, hipStream_t st, int ksize = 7);
+                              const float* mean, const float* stdv, int normalize, hipStream_t st, int ksize = 7, int pad = -1 /* top / left; -1: ksize / 2 */);
 
 // Dice loss (multilabel, from logits) and / or mean binary cross-entropy with logits + confusion counts, logits/target NCHW f32
 constexpr int DICE_NS = 4;                                   // doubles per (image, class): I, S, T, BCE sum

@@ -450,6 +450,47 @@ struct Builder {
     return o;
   }
   static Value mat_(int t) { Value v; v.t = t; v.bn = -1; return v; }
+  // ---- EfficientNet pieces (efficientnet_pytorch MBConvBlock, restated in oracle/nets.py; kernels in effnet.hip)
+  void set_bn_effnet(int bi) { P->bns[bi].eps = 1e-3f; P->bns[bi].momentum = 0.01f; }
+  // out = act(bn(y)) * drop_connect + post, materialised (swish has no lazy form in the conv kernels' staging)
+  int bnx(Value y, int act, int post, int dc_block, bool conv_bn) {
+    const TensorInfo t = P->tensors[y.t];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_BNX; op.y = y; op.up = act; op.post = post; op.oc0 = dc_block; op.out = o; op.conv_bn = conv_bn;
+    P->ops.push_back(op);
+    P->bns[y.bn].lazy = false;
+    return o;
+  }
+  // depthwise K x K conv (torch weight [C][1][K][K] -> arena [K][K][C]) + BatchNorm (statistics from the output tensor)
+  Value dwg(const std::string& name, int in, int K, int stride, int pad, const std::string& bn_name) {
+    const TensorInfo t = P->tensors[in];
+    const int OH = (t.H + stride - 1) / stride, OW = (t.W + stride - 1) / stride;      // TF "same"
+    const int o = tensor(t.N, OH, OW, t.C);
+    Op op; op.kind = OP_DWG; op.in = in; op.out = o; op.dwp = param(name + ".weight", OCTSEG_P_CONV, K, K, t.C, 1, 0); op.up = stride; op.oc0 = pad; op.wc0 = K;
+    P->ops.push_back(op);
+    P->fwd_macs += (double)t.N * OH * OW * t.C * K * K;
+    const int bi = bn(bn_name, t.C, o, false);
+    set_bn_effnet(bi);
+    stats_fin(bi, o);
+    Value v; v.t = o; v.bn = bi;
+    return v;
+  }
+  // squeeze-excite of an MBConv block: mean -> W1, b1 -> swish -> W2, b2 -> sigmoid gate (reduction widths 4 .. 160: a kernel of its own)
+  int se_effnet(const std::string& pre, int in, int rd) {
+    const TensorInfo t = P->tensors[in];
+    const int g = gap(in);
+    const int s = tensor(t.N, 1, 1, t.C);
+    Op f; f.kind = OP_SEFC; f.in = g; f.out = s; f.up = rd;
+    f.ins[0] = param(pre + "._se_reduce.weight", OCTSEG_P_CONV, 1, 1, rd, t.C, 0);
+    f.ins[1] = param(pre + "._se_reduce.bias", OCTSEG_P_VEC, 1, 1, rd, 1, 0);
+    f.ins[2] = param(pre + "._se_expand.weight", OCTSEG_P_CONV, 1, 1, t.C, rd, 0);
+    f.ins[3] = param(pre + "._se_expand.bias", OCTSEG_P_VEC, 1, 1, t.C, 1, 0);
+    P->ops.push_back(f);
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_SEGATE; op.in = in; op.ins[0] = s; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
   // parameters and buffers of a layer the graph never runs (smp's get_encoder(depth=3) keeps layer3 / layer4 in the module and in state_dict)
   void dead_conv(const std::string& name, int Cout, int Cin, int R) { param(name + ".weight", OCTSEG_P_CONV, R, R, Cout, Cin, 0); }
   void dead_bn(const std::string& name, int C, int any_tensor) { bn(name, C, any_tensor, false); }
@@ -549,7 +590,7 @@ static bool regnet_cfg(const std::string& enc, RegNetCfg& c) {
 }
 std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
   octseg_plan* P = b.P;
-  P->stem_k = 3;
+  P->stem_k = 3; P->stem_pad = 1;
   const int KP = 32;   // 3 * 3 * 3 = 27 padded
   P->col_tensor = b.tensor(P->B, P->H / 2, P->W / 2, KP, false);
   { Op op; op.kind = OP_STEM_COL; op.out = P->col_tensor; P->ops.push_back(op); }
@@ -591,6 +632,84 @@ std::vector<int> build_regnet(Builder& b, const RegNetCfg& cfg, int depth) {
     }
     if (si + 2 <= depth) feats.push_back(x);
   }
+  return feats;
+}
+
+// efficientnet_pytorch's EfficientNet as smp's EfficientNetEncoder runs it (oracle/nets.py EfficientNetEncoder; reference configs/tune.yaml:
+// 25-28: efficientnet-b0 / -b5 / -b7): stem 3x3 s2 (static "same" padding: top / left 0) + BN + swish, MBConv blocks -- expand 1x1 + BN + swish
+// (expand ratio 6), depthwise k3 / k5 stride 1 / 2 + BN + swish, squeeze-excite with swish, project 1x1 + BN, id skip with drop_connect
+// where stride 1 and equal widths --, features behind smp's stage indices; _conv_head / _bn1 stay as never-run parameters.
+struct EffBlock { int k, stride, expand, cin, cout, se, pad; };
+struct EffCfg { int stem, head, stage_idx[3]; std::vector<EffBlock> blocks; };
+static bool effnet_cfg(const std::string& enc, EffCfg& c) {
+  double w, d; int size;
+  if (enc == "efficientnet-b0") { w = 1.0; d = 1.0; size = 224; int si[3] = {3, 5, 9}; memcpy(c.stage_idx, si, sizeof si); }
+  else if (enc == "efficientnet-b5") { w = 1.6; d = 2.2; size = 456; int si[3] = {8, 13, 27}; memcpy(c.stage_idx, si, sizeof si); }
+  else if (enc == "efficientnet-b7") { w = 2.0; d = 3.1; size = 600; int si[3] = {11, 18, 38}; memcpy(c.stage_idx, si, sizeof si); }
+  else return false;
+  auto rf = [&](int f) { const double x = f * w; int n = std::max(8, (int)(x + 4) / 8 * 8); if (n < 0.9 * x) n += 8; return n; };
+  auto same_pad_top = [](int ih, int k, int s) { const int oh = (ih + s - 1) / s; const int pad = std::max((oh - 1) * s + k - ih, 0); return pad / 2; };
+  static const int B[7][6] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80}, {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192},
+                              {1, 3, 1, 6, 192, 320}};
+  c.stem = rf(32); c.head = rf(1280); c.blocks.clear();
+  size = (size + 1) / 2;       // behind the stem (its own static padding: top 0 for the even nominal sizes 224 / 456 / 600)
+  for (auto& r : B) {
+    const int rep = (int)ceil(d * r[0]), cin = rf(r[4]), cout = rf(r[5]);
+    for (int j = 0; j < rep; ++j) {
+      const int st = j == 0 ? r[2] : 1, ci = j == 0 ? cin : cout;
+      c.blocks.push_back(EffBlock{r[1], st, r[3], ci, cout, std::max(1, (int)(ci * 0.25)), same_pad_top(size, r[1], st)});
+      size = (size + st - 1) / st;
+    }
+  }
+  return true;
+}
+std::vector<int> build_effnet(Builder& b, const EffCfg& cfg, int depth) {
+  octseg_plan* P = b.P;
+  P->stem_k = 3; P->stem_pad = 0;
+  const int KP = 32;
+  P->col_tensor = b.tensor(P->B, P->H / 2, P->W / 2, KP, false);
+  { Op op; op.kind = OP_STEM_COL; op.out = P->col_tensor; P->ops.push_back(op); }
+  Value ystem = b.conv("encoder._conv_stem", {{mat(P->col_tensor), 0}}, cfg.stem, 1, 1, 0, "encoder._bn0", false, false, false, true);
+  b.set_bn_effnet(ystem.bn);
+  std::vector<int> feats;
+  int x = b.bnx(ystem, 1, -1, -1, true);
+  feats.push_back(x);
+  const int nb = (int)cfg.blocks.size();
+  int stage = 0;      // blocks [0, stage_idx[0]) -> feature 2, ...
+  bool live = true;
+  for (int bi = 0; bi < nb; ++bi) {
+    const EffBlock& e = cfg.blocks[bi];
+    const std::string pre = "encoder._blocks." + std::to_string(bi);
+    const int mid = e.cin * e.expand;
+    if (stage < 3 && bi == cfg.stage_idx[stage]) { feats.push_back(x); ++stage; if ((int)feats.size() >= depth) live = false; }
+    if (!live) {        // (smp encoder_depth 3: the later blocks keep parameters and buffers, no op)
+      if (e.expand != 1) { b.dead_conv(pre + "._expand_conv", mid, e.cin, 1); b.dead_bn(pre + "._bn0", mid, x); }
+      b.param(pre + "._depthwise_conv.weight", OCTSEG_P_CONV, e.k, e.k, mid, 1, 0); b.dead_bn(pre + "._bn1", mid, x);
+      b.dead_conv(pre + "._se_reduce", e.se, mid, 1); b.param(pre + "._se_reduce.bias", OCTSEG_P_VEC, 1, 1, e.se, 1, 0);
+      b.dead_conv(pre + "._se_expand", mid, e.se, 1); b.param(pre + "._se_expand.bias", OCTSEG_P_VEC, 1, 1, mid, 1, 0);
+      b.dead_conv(pre + "._project_conv", e.cout, mid, 1); b.dead_bn(pre + "._bn2", e.cout, x);
+      continue;
+    }
+    int t = x;
+    if (e.expand != 1) {
+      Value v = b.conv(pre + "._expand_conv", {{mat(x), 0}}, mid, 1, 1, 0, pre + "._bn0", false);
+      b.set_bn_effnet(v.bn);
+      t = b.bnx(v, 1, -1, -1, true);
+    }
+    Value vd = b.dwg(pre + "._depthwise_conv", t, e.k, e.stride, e.pad, pre + "._bn1");
+    const int td = b.bnx(vd, 1, -1, -1, false);
+    const int ts = b.se_effnet(pre, td, e.se);
+    Value vp = b.conv(pre + "._project_conv", {{mat(ts), 0}}, e.cout, 1, 1, 0, pre + "._bn2", false);
+    b.set_bn_effnet(vp.bn);
+    const bool id_skip = e.stride == 1 && e.cin == e.cout;
+    int dc = -1;
+    if (id_skip && bi > 0) { dc = (int)P->dc_rates.size(); P->dc_rates.push_back(0.2f * (float)bi / (float)nb); }   // (block 0: rate 0 -> no drop)
+    x = b.bnx(vp, 0, id_skip ? x : -1, dc, true);
+  }
+  if (live) feats.push_back(x);
+  // smp deletes only _fc: the classifier's 1x1 conv and BatchNorm stay in the module and in state_dict
+  b.dead_conv("encoder._conv_head", cfg.head, cfg.blocks.back().cout, 1);
+  b.dead_bn("encoder._bn1", cfg.head, x);
   return feats;
 }
 
@@ -684,7 +803,12 @@ static int build_plan(octseg_plan* P) {
   std::vector<int> f;
   RegNetCfg rcfg;
   const bool regnet = regnet_cfg(P->encoder, rcfg);
-  if (regnet) {
+  EffCfg ecfg;
+  const bool effnet = effnet_cfg(P->encoder, ecfg);
+  if (effnet) {
+    if (P->arch == "deeplabv3plus" || dlv3) return fail(OCTSEG_UNSUPPORTED_ARCH, "EfficientNet encoders cannot be dilated (smp raises for DeepLabV3 / DeepLabV3+ over them too)");
+    f = build_effnet(b, ecfg, P->arch == "pspnet" ? 3 : 5);
+  } else if (regnet) {
     if (P->arch == "deeplabv3plus" || dlv3) return fail(OCTSEG_UNSUPPORTED_ARCH, "the dilated RegNet encoders (smp make_dilated) are not built");
     if ((P->arch == "linknet" && (rcfg.w[3] / 4) % 8 != 0) || (P->arch == "pspnet" && (rcfg.w[1] / 4) % 8 != 0))   // LinkNet's decoder blocks and PSPNet's pyramid branches run on a QUARTER of a feature's channels
       return fail(OCTSEG_UNSUPPORTED_ARCH, P->arch + " over " + P->encoder + ": its decoder narrows a feature to a quarter of its channels (" +
@@ -738,6 +862,9 @@ static int build_plan(octseg_plan* P) {
     for (int i = 0; i < 5; ++i) {
       const std::string pre = "decoder.blocks." + std::to_string(i) + ".block";
       const int cin = ch[i], mid = cin / 4, cout = ch[i + 1];
+      if (mid % 8 != 0)
+        return fail(OCTSEG_UNSUPPORTED_ARCH, "linknet over " + P->encoder + ": its decoder narrows a feature to a quarter of its channels (" +
+                    std::to_string(cin) + " / 4 is not a multiple of the 8-channel vector the NHWC kernels move)");
       Value v1 = b.conv(pre + ".0.0", {{x, 0}}, mid, 1, 1, 0, pre + ".0.1", false);
       Value v2 = b.conv(pre + ".1.0", {{v1, 0}}, mid, 4, 2, 1, pre + ".1.1", true, true);
       Value v3 = b.conv(pre + ".2.0", {{v2, 0}}, cout, 1, 1, 0, pre + ".2.1", false);
@@ -808,6 +935,9 @@ static int build_plan(octseg_plan* P) {
     const int X = f[2];
     const TensorInfo tx = P->tensors[X];
     const int sizes[4] = {1, 2, 3, 6};
+    if ((tx.C / 4) % 8 != 0)
+      return fail(OCTSEG_UNSUPPORTED_ARCH, "pspnet over " + P->encoder + ": its pyramid branches run on a quarter of the feature's channels (" +
+                  std::to_string(tx.C) + " / 4 is not a multiple of the 8-channel vector the NHWC kernels move)");
     std::vector<ConvSrc> cat;
     for (int i = 0; i < 4; ++i) {
       const std::string pre = "decoder.psp.blocks." + std::to_string(i) + ".pool.1";
@@ -866,7 +996,7 @@ static int build_plan(octseg_plan* P) {
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (!regnet && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
+  if (!regnet && !effnet && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -971,7 +1101,7 @@ static int build_plan(octseg_plan* P) {
   P->bn_jobs.clear(); P->bn_prefix.clear(); P->bn_total = 0;
   for (auto& b : P->bns) {
     P->bn_prefix.push_back(P->bn_total);
-    P->bn_jobs.push_back(BnEvalJob{P->params[b.gamma].off, P->params[b.beta].off, b.rm_off, b.rv_off, b.ss_off, b.C, ~(size_t)0});
+    P->bn_jobs.push_back(BnEvalJob{P->params[b.gamma].off, P->params[b.beta].off, b.rm_off, b.rv_off, b.ss_off, b.C, ~(size_t)0, b.eps});
     P->bn_total += (unsigned)b.C;
   }
   for (auto& L : P->convs)   // a biased conv in front of a BatchNorm (LinkNet's ConvTranspose2d): its bias folds into the eval shift
@@ -999,6 +1129,8 @@ static int build_plan(octseg_plan* P) {
     for (auto& op : P->ops)
       if (op.kind == OP_SEGATE) { const TensorInfo& t = P->tensors[op.in]; se_part = std::max(se_part, (size_t)t.N * se_dgate_shares(t.H * t.W) * t.C * sizeof(float)); }
     P->se_part_off = off; off += align_up(se_part);
+    for (auto& op : P->ops)
+      if (op.kind == OP_SEFC) { const TensorInfo& t = P->tensors[op.in]; op.aux_off = off; off += align_up((size_t)2 * t.N * op.up * sizeof(float)); }
   }
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * DICE_NS * sizeof(double));   // totals + per-image replicas
@@ -1162,7 +1294,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         const TensorInfo& t = P->tensors[op.out];
         // (2-byte dtypes: the stem conv gathers its im2col rows straight from the frame in LDS, thin.hip KSTEM -- no 634 MB tensor)
         if (!(P->stem_k == 7 && thin_stem_eligible(P->dtype)))
-          HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st, P->stem_k));
+          HIPCHK(launch_stem_im2col(P->dtype, image, E.act(op.out), P->B, P->H, P->W, t.C, mean, stdv, normalize, st, P->stem_k, P->stem_pad));
         tseq[op.out] = stamp;
         break;
       }
@@ -1235,11 +1367,11 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         rc = need(lane, tseq[b.y]);   // same lane as its conv by construction; kept for safety
         if (rc) return rc;
         if (E.train && b.count <= (double)BN_SMALL_COUNT)   // small tensors (pooled ASPP branch, 2x2 .. 16x16 maps): exact two-pass statistics
-          HIPCHK(launch_bn_finalize_small(P->dtype, E.act(b.y), (int)b.count, b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f,
-                                          1e-5f, E.bn_scale(op.bn), E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), st));
+          HIPCHK(launch_bn_finalize_small(P->dtype, E.act(b.y), (int)b.count, b.C, gamma, beta, E.buffers + b.rm_off, E.buffers + b.rv_off, b.momentum,
+                                          b.eps, E.bn_scale(op.bn), E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), st));
         else if (E.train)
           HIPCHK(launch_bn_finalize_train(slab_l, b.rows, b.C, b.count, gamma, beta,
-                                          E.buffers + b.rm_off, E.buffers + b.rv_off, 0.1f, 1e-5f, E.bn_scale(op.bn),
+                                          E.buffers + b.rm_off, E.buffers + b.rv_off, b.momentum, b.eps, E.bn_scale(op.bn),
                                           E.bn_shift(op.bn), E.bn_mean(op.bn), E.bn_rstd(op.bn), part_l, cnt_l, st));
         // (eval: done for every BatchNorm at once in front of the loop)
         bseq[op.bn] = E.train ? stamp : 1;
@@ -1348,6 +1480,47 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       case OP_SEGATE: {
         const TensorInfo& t = P->tensors[op.in];
         HIPCHK(launch_se_gate(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), t.N, t.H * t.W, t.C, 0, st));
+        break;
+      }
+      case OP_DWG: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        DwgArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = E.act(op.in); a.out = E.act(op.out); a.w = E.params + P->params[op.dwp].off;
+        a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.OH = to.H; a.OW = to.W; a.K = op.wc0; a.stride = op.up; a.pad = op.oc0;
+        HIPCHK(launch_dwg_fwd(P->dtype, a, st));
+        break;
+      }
+      case OP_BNX: {
+        const TensorInfo& t = P->tensors[op.out];
+        rc = need_val(lane, op.y); if (rc) return rc;
+        BnxArgs a;
+        memset(&a, 0, sizeof(a));
+        a.y = E.act(op.y.t);
+        if (!(folded && op.conv_bn)) { a.scale = E.bn_scale(op.y.bn); a.shift = E.bn_shift(op.y.bn); }   // (eval: a conv's BatchNorm is in its epilogue already)
+        if (E.train && op.oc0 >= 0) {
+          if (P->drop_connect == nullptr)
+            return fail(OCTSEG_BAD_ARG, "EfficientNet training forward: no drop_connect factors set (octseg_plan_set_drop_connect: device float [" +
+                                        std::to_string(P->dc_rates.size()) + "][B] of 0 or 1 / (1 - rate))");
+          a.dscale = P->drop_connect + (size_t)op.oc0 * t.N;
+        }
+        a.post = op.post >= 0 ? E.act(op.post) : nullptr;
+        a.out = E.act(op.out); a.npix = (size_t)t.N * t.H * t.W; a.hw = t.H * t.W; a.C = t.C; a.act = op.up;
+        HIPCHK(launch_bnx_fwd(P->dtype, a, st));
+        tseq[op.out] = stamp;
+        break;
+      }
+      case OP_SEFC: {
+        const TensorInfo& t = P->tensors[op.in];
+        SefcArgs a;
+        memset(&a, 0, sizeof(a));
+        a.m = E.act(op.in); a.s = E.act(op.out);
+        a.w1 = E.params + P->params[op.ins[0]].off; a.b1 = E.params + P->params[op.ins[1]].off;
+        a.w2 = E.params + P->params[op.ins[2]].off; a.b2 = E.params + P->params[op.ins[3]].off;
+        a.h = (float*)(E.ws + op.aux_off); a.dh = a.h + (size_t)t.N * op.up;
+        a.N = t.N; a.C = t.C; a.R = op.up;
+        HIPCHK(launch_sefc_fwd(P->dtype, a, st));
         break;
       }
       case OP_RESIZE: {
@@ -1718,6 +1891,51 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         break;
       }
       case OP_STATS: break;
+      case OP_DWG: {
+        const TensorInfo& ti = P->tensors[op.in];
+        const TensorInfo& to = P->tensors[op.out];
+        DwgArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = E.act(op.in); a.out = E.grad(op.out); a.w = E.params + P->params[op.dwp].off; a.dw = E.grads + P->params[op.dwp].off;
+        a.N = ti.N; a.H = ti.H; a.W = ti.W; a.C = ti.C; a.OH = to.H; a.OW = to.W; a.K = op.wc0; a.stride = op.up; a.pad = op.oc0;
+        HIPCHK(launch_dwg_bwd_w(P->dtype, a, E.st));
+        if (ti.need_grad) {
+          a.gin = E.grad(op.in); a.accum = E.claim(op.in);
+          HIPCHK(launch_dwg_bwd_data(P->dtype, a, E.st));
+        }
+        break;
+      }
+      case OP_BNX: {        // gradient wrt bn(y) into grad(y) (act', drop_connect factor), the ordinary BatchNorm backward on it in place; post: + g
+        const TensorInfo& t = P->tensors[op.out];
+        BnxArgs a;
+        memset(&a, 0, sizeof(a));
+        a.y = E.act(op.y.t); a.scale = E.bn_scale(op.y.bn); a.shift = E.bn_shift(op.y.bn);
+        a.dscale = op.oc0 >= 0 ? P->drop_connect + (size_t)op.oc0 * t.N : nullptr;
+        a.post = E.grad(op.out); a.out = E.grad(op.y.t);
+        a.npix = (size_t)t.N * t.H * t.W; a.hw = t.H * t.W; a.C = t.C; a.act = op.up;
+        HIPCHK(launch_bnx_bwd(P->dtype, a, E.st));
+        rc = bn_backward(E, op.y.bn, E.grad(op.y.t), 0, nullptr);
+        if (rc) return rc;
+        if (op.post >= 0 && P->tensors[op.post].need_grad) {
+          const int acc = E.claim(op.post);
+          HIPCHK(launch_masked_accum(P->dtype, E.grad(op.post), E.grad(op.out), nullptr, (size_t)t.N * t.H * t.W * t.C, acc ? 0 : 1, E.st));
+        }
+        break;
+      }
+      case OP_SEFC: {
+        const TensorInfo& t = P->tensors[op.in];
+        SefcArgs a;
+        memset(&a, 0, sizeof(a));
+        a.m = E.act(op.in); a.ds = E.grad(op.out); a.dm = E.grad(op.in);
+        a.w1 = E.params + P->params[op.ins[0]].off; a.w2 = E.params + P->params[op.ins[2]].off;
+        a.dw1 = E.grads + P->params[op.ins[0]].off; a.db1 = E.grads + P->params[op.ins[1]].off;
+        a.dw2 = E.grads + P->params[op.ins[2]].off; a.db2 = E.grads + P->params[op.ins[3]].off;
+        a.h = (float*)(E.ws + op.aux_off); a.dh = a.h + (size_t)t.N * op.up;
+        a.N = t.N; a.C = t.C; a.R = op.up;
+        HIPCHK(launch_sefc_bwd(P->dtype, a, E.st));
+        E.ginit[op.in] = 1;
+        break;
+      }
       case OP_SEGATE: {     // d x (+)= g * sigmoid(s);  d s = sigmoid'(s) * sum_p g * x
         const TensorInfo& t = P->tensors[op.in];
         HIPCHK(launch_se_dgate(P->dtype, E.grad(op.out), E.act(op.in), E.act(op.ins[0]), E.grad(op.ins[0]), (float*)(E.ws + P->se_part_off), t.N, t.H * t.W,
@@ -1856,8 +2074,8 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
   if (d->batch <= 0 || d->classes <= 0 || d->classes > 16) return fail(OCTSEG_BAD_SHAPE, "batch > 0 and 1 <= classes <= 16 required");
   const std::string enc = lower(d->encoder);
   if (enc != "resnet18" && enc != "resnet34" && enc != "resnet50" && enc != "resnet101" && enc != "resnet152" && enc != "timm-regnetx_002" &&
-      enc != "timm-regnetx_064" && enc != "timm-regnety_120")
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152 | timm-regnetx_002 | timm-regnetx_064 | timm-regnety_120)");
+      enc != "timm-regnetx_064" && enc != "timm-regnety_120" && enc != "efficientnet-b0" && enc != "efficientnet-b5" && enc != "efficientnet-b7")
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown encoder '" + enc + "' (resnet18 | resnet34 | resnet50 | resnet101 | resnet152 | timm-regnetx_002 | timm-regnetx_064 | timm-regnety_120 | efficientnet-b0 | efficientnet-b5 | efficientnet-b7)");
   octseg_plan* P = new octseg_plan();
   P->arch = lower(d->arch); P->encoder = enc; P->classes = d->classes;
   P->B = d->batch; P->H = d->height; P->W = d->width; P->dtype = d->dtype;
@@ -2111,6 +2329,15 @@ int octseg_plan_set_loss(octseg_plan* p, int kind) {
   p->loss_kind = kind;
   return OCTSEG_OK;
 }
+// EfficientNet's drop_connect (efficientnet_pytorch.utils.drop_connect inside MBConvBlock.forward): the caller draws the per-sample keep
+// decisions -- randomness stays with the caller, as with Dropout -- and hands over the FACTORS keep / (1 - rate).
+int octseg_plan_set_drop_connect(octseg_plan* p, const float* factors_dev) {
+  if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
+  p->drop_connect = factors_dev;
+  return OCTSEG_OK;
+}
+int octseg_plan_num_drop_connect(const octseg_plan* p) { return p ? (int)p->dc_rates.size() : 0; }
+float octseg_plan_drop_connect_rate(const octseg_plan* p, int i) { return (p && i >= 0 && i < (int)p->dc_rates.size()) ? p->dc_rates[i] : -1.f; }
 int octseg_plan_set_train_graph(octseg_plan* p, int enable) {
   if (!p) return fail(OCTSEG_BAD_ARG, "null argument");
   p->tgraph_enabled = enable != 0;

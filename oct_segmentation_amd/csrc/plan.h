@@ -39,6 +39,7 @@ struct BNInfo {
   int rows;                 // slab rows produced by the conv epilogue
   bool lazy;                // consumed by conv sources (relu(bn(y))) -> BN backward runs in place
   int y;                    // tensor it normalises
+  float eps = 1e-5f, momentum = 0.1f;   // torch defaults; efficientnet_pytorch: 1e-3 / 0.01
 };
 
 // GroupNorm(32) + ReLU of the FPN decoder's Conv3x3GNReLU (smp decoders/fpn): per-(image, group) statistics, no running buffers
@@ -94,7 +95,11 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               // DeepLabV3 (deeplab.hip)
               OP_MOSAIC,     // out = mosaic of the rate^2 sub-grids of in (oc0 = 1), or in's mosaic gathered back (oc0 = 0); rate = up
               OP_STATS,      // BatchNorm partial sums of tensor `in` for BN `bn` (its producer is not a conv epilogue)
-              OP_SEGATE };   // out = in * sigmoid(ins[0] [N][1][1][C]): the squeeze-excite gate (timm SEModule, RegNetY; se.hip)
+              OP_SEGATE,     // out = in * sigmoid(ins[0] [N][1][1][C]): the squeeze-excite gate (timm SEModule, RegNetY; se.hip)
+              // EfficientNet (effnet.hip)
+              OP_DWG,        // out = depthwise K x K (wc0) stride `up` conv of in, top/left padding oc0, weights param dwp [K][K][C]
+              OP_BNX,        // out = act(bn(y)) * drop_connect[n] + post: act = up (0 identity, 1 swish), drop-connect block oc0 (-1: none)
+              OP_SEFC };     // out [N][1][1][C] = W2 swish(W1 in + b1) + b2: params ins[0..3] = w1, b1, w2, b2; up = reduction channels
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -109,6 +114,8 @@ struct Op {
   int ins[4] = {-1, -1, -1, -1};   // OP_MERGE
   int dwp = -1, oc0 = 0, wc0 = 0;  // OP_DW: weight parameter, first output channel, first weight channel
   bool dw_first = true;            // OP_DW: first writer of the parameter's gradient slice? (all slices accumulate: atomics)
+  size_t aux_off = 0;              // OP_SEFC: float scratch h [N][R], dh [N][R] in the workspace
+  bool conv_bn = false;            // OP_BNX: the BatchNorm is fed (and, in eval, folded) by a conv epilogue
 };
 
 }  // namespace octseg
@@ -140,6 +147,9 @@ struct octseg_plan {
   size_t pool_idx_off = 0;                   // maxpool: window position of every maximum (1 byte per output element)
   size_t tmp_off = 0, tmp_bytes = 0;         // dgrad temp for upsampled sources
   size_t se_part_off = 0;                    // float scratch of the squeeze-excite gate's own gradient (se.hip)
+  int stem_pad = 3;                          // top / left padding of the stem conv (3: ResNet 7x7, 1: RegNet 3x3, 0: EfficientNet's static 'same')
+  const float* drop_connect = nullptr;       // EfficientNet: id-skip factors of the next training forward, device float [blocks with id skip][B]
+  std::vector<float> dc_rates;               // their drop_connect rates (0.2 * block index / blocks)
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
   int loss_kind = 0;                         // LOSS_DICE | LOSS_BCE | LOSS_DICE_BCE (octseg_plan_set_loss)
   size_t dice_off = 0;                       // double sums[1 + B][C][DICE_NS]: totals, then one replica per image

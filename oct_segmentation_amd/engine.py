@@ -22,7 +22,10 @@ _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channel
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
 _ENCODERS = ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
              # timm RegNet through smp's RegNetEncoder (reference configs/tune.yaml:19-24); grouped 3x3 convs run as per-group launches
-             'timm-regnetx_002', 'timm-regnetx_064', 'timm-regnety_120')   # (RegNetY: + squeeze-excite gates, csrc/se.hip)
+             'timm-regnetx_002', 'timm-regnetx_064', 'timm-regnety_120',   # (RegNetY: + squeeze-excite gates, csrc/se.hip)
+             # efficientnet_pytorch through smp's EfficientNetEncoder (configs/tune.yaml:25-28): MBConv blocks, csrc/effnet.hip
+             'efficientnet-b0', 'efficientnet-b5', 'efficientnet-b7')
+_EFFNET_STAGE1 = {'efficientnet-b0': 5, 'efficientnet-b5': 13, 'efficientnet-b7': 18}   # smp _stage_idxs[1]: first block behind the stride-8 feature
 
 
 def get_preprocessing_params(encoder_name, pretrained='imagenet'):
@@ -210,6 +213,9 @@ class SegNet(nn.Module):
         # [B, H/16, W/16, 256] NHWC per element for DeepLabV3+ -- unless `dropout_keep` holds one (tests inject the oracle's;
         # DeepLabV3+ also accepts torch's NCHW [B, 256, H/16, W/16]); eval ignores it.
         self.dropout_keep = None
+        # EfficientNet: drop_connect on the id skips of the MBConv blocks.  Training forwards draw floor(1 - rate + U[0, 1)) per block and
+        # sample (torch's RNG) unless `drop_connect_keep` holds a [blocks][B] pattern of 0 / 1 (tests inject the oracle's); eval ignores it
+        self.drop_connect_keep = None
         self._param_epoch = 0   # bumped by writers that bypass torch's version counter (the fused optimizer)
         self._buffer_epoch = 0  # the same for bn_buffers (every train-mode forward)
         # parameter table from a shape-independent probe plan (32x32 is the smallest legal input)
@@ -243,6 +249,11 @@ class SegNet(nn.Module):
         # state_dict without ever running them: torch optimizers skip parameters whose gradient is None, so weight decay must not
         # reach them here either -- the fused optimizer steps over the live ranges only
         dead = (('encoder.s3.', 'encoder.s4.') if encoder_name.startswith('timm-regnet') else ('encoder.layer3.', 'encoder.layer4.')) if a == 'pspnet' else ()
+        if encoder_name.startswith('efficientnet-'):      # smp deletes only _fc: the classifier's conv / BatchNorm stay in state_dict and never run
+            nblk = 1 + max(int(p['name'].split('.')[2]) for p in self.param_table if p['name'].startswith('encoder._blocks.'))
+            dead = ('encoder._conv_head.', 'encoder._bn1.')
+            if a == 'pspnet':
+                dead += tuple(f'encoder._blocks.{k}.' for k in range(_EFFNET_STAGE1[encoder_name], nblk))
         self._dead_prefixes = dead
         self.live_ranges, lo = [], 0
         for p in sorted(self.param_table, key=lambda q: q['offset']):
@@ -346,6 +357,8 @@ class SegNet(nn.Module):
                         t.fill_(1.0)
                         if self.encoder_name.startswith('timm-regnet') and name.endswith('.conv3.bn.weight'):
                             t.zero_()      # timm RegNet(zero_init_last=True): the block's last BatchNorm starts at gamma = 0
+                elif name.startswith('encoder.') and self.encoder_name.startswith('efficientnet-'):
+                    nn.init.kaiming_uniform_(t, a=5 ** 0.5, generator=g)     # efficientnet_pytorch: torch's Conv2d default
                 elif name.startswith('encoder.'):
                     nn.init.kaiming_normal_(t, mode='fan_out', nonlinearity='relu', generator=g)
                 elif name.startswith('segmentation_head.'):
@@ -374,7 +387,7 @@ class SegNet(nn.Module):
                 base = prefix + b['name']
                 sd[base + '.running_mean'] = self.bn_buffers[b['mean_offset']:b['mean_offset'] + b['C']].clone()
                 sd[base + '.running_var'] = self.bn_buffers[b['var_offset']:b['var_offset'] + b['C']].clone()
-                dead_bn = bool(self._dead_prefixes) and b['name'].startswith(self._dead_prefixes)     # never ran: torch's counter stays 0
+                dead_bn = bool(self._dead_prefixes) and (b['name'] + '.').startswith(self._dead_prefixes)     # never ran: torch's counter stays 0
                 sd[base + '.num_batches_tracked'] = torch.zeros_like(self.num_batches_tracked) if dead_bn else self.num_batches_tracked.clone()
         return sd
 
@@ -403,7 +416,7 @@ class SegNet(nn.Module):
                     if k in state_dict:
                         self.bn_buffers[off:off + b['C']] = state_dict[k].to(self.device, torch.float32)
                 k = f"{b['name']}.num_batches_tracked"
-                if k in state_dict and not (self._dead_prefixes and b['name'].startswith(self._dead_prefixes)):
+                if k in state_dict and not (self._dead_prefixes and (b['name'] + '.').startswith(self._dead_prefixes)):
                     self.num_batches_tracked.copy_(state_dict[k])
         self.params_changed()   # the views write through arena.data, which torch's version counter does not see
         return nn.modules.module._IncompatibleKeys(missing, unexpected)
@@ -525,6 +538,18 @@ class SegNet(nn.Module):
             plan.seen_buffers = bver
         if train:
             plan.stem_frame = x        # octseg.h: `image` must outlive the backward (the stem weight gradient reads it again)
+        if train and self.encoder_name.startswith('efficientnet-'):
+            lib = L.lib()
+            nb = lib.octseg_plan_num_drop_connect(plan.handle)
+            rates = torch.tensor([lib.octseg_plan_drop_connect_rate(plan.handle, i) for i in range(nb)], dtype=torch.float32, device=x.device)
+            keep = self.drop_connect_keep
+            if keep is None:
+                keep = torch.floor((1.0 - rates).view(-1, 1) + torch.rand(nb, B, device=x.device))
+            keep = keep.to(x.device, torch.float32)
+            if tuple(keep.shape) != (nb, B):
+                raise ValueError(f'drop_connect_keep must be [{nb}, {B}] of 0 / 1, got {tuple(keep.shape)}')
+            plan.dc_factors = (keep / (1.0 - rates).view(-1, 1)).contiguous()     # kept alive with the plan: the backward reads it too
+            L.check(lib.octseg_plan_set_drop_connect(plan.handle, L.ptr(plan.dc_factors)))
         if self._has_dropout() and train:
             keep = self._draw_keep(B, H, W, x.device)
             plan.drop_keep = keep      # the backward of this step reads it too: keep it alive with the plan

@@ -270,6 +270,144 @@ class RegNetEncoder(nn.Module):
         return feats
 
 
+
+# ------------------------------------------------------------------------------------------------ EfficientNet encoders
+# smp 0.3.3 ``encoders/efficientnet.py`` (EfficientNetEncoder over efficientnet_pytorch 0.7.1's ``EfficientNet``), the ``efficientnet-b0 / b5 /
+# b7`` rows of the reference's sweep (configs/tune.yaml:25-28).  Neither package is installed here: restated from the published sources --
+# block arguments, round_filters / round_repeats, Conv2dStaticSamePadding (TF "same" padding FIXED at construction from the model's nominal
+# image size: 224 / 456 / 600), MBConvBlock (expand 1x1 -> depthwise k3 / k5 -> squeeze-excite with swish -> project 1x1, id skip with
+# drop_connect), BatchNorm eps 1e-3 / momentum 0.01, attribute names (``_conv_stem``, ``_bn0``, ``_blocks.{i}._expand_conv`` ...) as upstream
+# so that state_dict keys equal a reference checkpoint's; ``_conv_head`` / ``_bn1`` stay in the module (smp deletes only ``_fc``) and never
+# run.  Pinned by the published parameter counts (tests/test_oracle.py).
+_EFFNET_BLOCKS = [   # (repeats, kernel, stride, expand, in, out): efficientnet_pytorch's BlockDecoder strings r1_k3_s11_e1_i32_o16_se0.25 ...
+    (1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80), (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192),
+    (1, 3, 1, 6, 192, 320)]
+_EFFNET_CFG = {   # width, depth, nominal image size; smp's stage_idxs
+    'efficientnet-b0': dict(w=1.0, d=1.0, size=224, stage_idxs=(3, 5, 9, 16)),
+    'efficientnet-b5': dict(w=1.6, d=2.2, size=456, stage_idxs=(8, 13, 27, 39)),
+    'efficientnet-b7': dict(w=2.0, d=3.1, size=600, stage_idxs=(11, 18, 38, 55)),
+}
+
+
+def effnet_round_filters(filters, w, divisor=8):
+    filters *= w
+    new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+    if new < 0.9 * filters:
+        new += divisor
+    return int(new)
+
+
+def effnet_block_list(name):
+    """[(kernel, stride, expand, cin, cout, se_channels, (pad_top, pad_bottom) of the depthwise conv)] per block, plus the stem / head widths
+    and the stem's padding: what EfficientNet.__init__ builds, static paddings included."""
+    cfg = _EFFNET_CFG[name]
+    size = cfg['size']
+
+    def same_pad(ih, k, s):
+        oh = -(-ih // s)
+        pad = max((oh - 1) * s + (k - 1) + 1 - ih, 0)
+        return (pad // 2, pad - pad // 2)
+
+    stem_pad = same_pad(size, 3, 2)
+    size = -(-size // 2)
+    blocks = []
+    for rep, k, st, e, cin, cout in _EFFNET_BLOCKS:
+        cin, cout = effnet_round_filters(cin, cfg['w']), effnet_round_filters(cout, cfg['w'])
+        rep = int(math.ceil(cfg['d'] * rep))
+        for j in range(rep):
+            s_j = st if j == 0 else 1
+            c_j = cin if j == 0 else cout
+            blocks.append((k, s_j, e, c_j, cout, max(1, int(c_j * 0.25)), same_pad(size, k, s_j)))
+            size = -(-size // s_j)
+    return dict(stem=effnet_round_filters(32, cfg['w']), stem_pad=stem_pad, head=effnet_round_filters(1280, cfg['w']), blocks=blocks)
+
+
+for _n, _c in _EFFNET_CFG.items():
+    _bl = effnet_block_list(_n)
+    ENCODER_CHANNELS[_n] = (3, _bl['stem']) + tuple(_bl['blocks'][i - 1][4] for i in _c['stage_idxs'])
+
+
+class StaticSamePadConv2d(nn.Conv2d):
+    """efficientnet_pytorch Conv2dStaticSamePadding: ZeroPad2d fixed at construction (pad = (top, bottom), the same for columns), then the
+    conv without padding."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, bias=False, pad=(0, 0)):
+        super().__init__(cin, cout, k, stride, 0, groups=groups, bias=bias)
+        self.pad = pad
+
+    def forward(self, x):
+        if self.pad != (0, 0):
+            x = F.pad(x, (self.pad[0], self.pad[1], self.pad[0], self.pad[1]))
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, k, stride, expand, cin, cout, se_ch, pad):
+        super().__init__()
+        mid = cin * expand
+        self.expand = expand != 1
+        self.id_skip = stride == 1 and cin == cout
+        bn = dict(momentum=0.01, eps=1e-3)
+        if self.expand:
+            self._expand_conv = StaticSamePadConv2d(cin, mid, 1)
+            self._bn0 = nn.BatchNorm2d(mid, **bn)
+        self._depthwise_conv = StaticSamePadConv2d(mid, mid, k, stride, groups=mid, pad=pad)
+        self._bn1 = nn.BatchNorm2d(mid, **bn)
+        self._se_reduce = StaticSamePadConv2d(mid, se_ch, 1, bias=True)
+        self._se_expand = StaticSamePadConv2d(se_ch, mid, 1, bias=True)
+        self._project_conv = StaticSamePadConv2d(mid, cout, 1)
+        self._bn2 = nn.BatchNorm2d(cout, **bn)
+        self.drop_mask = None          # [B] float 0 / 1: injected drop_connect pattern of the next training forward (None: draw)
+
+    def forward(self, inputs, drop_connect_rate=None):
+        x = inputs
+        if self.expand:
+            x = F.silu(self._bn0(self._expand_conv(x)))
+        x = F.silu(self._bn1(self._depthwise_conv(x)))
+        sq = F.adaptive_avg_pool2d(x, 1)
+        sq = self._se_expand(F.silu(self._se_reduce(sq)))
+        x = torch.sigmoid(sq) * x
+        x = self._bn2(self._project_conv(x))
+        if self.id_skip:
+            if drop_connect_rate and self.training:
+                keep = 1.0 - drop_connect_rate
+                m = self.drop_mask if self.drop_mask is not None else torch.floor(keep + torch.rand(x.shape[0]))
+                x = x / keep * m.to(x.dtype).view(-1, 1, 1, 1)
+            x = x + inputs
+        return x
+
+
+class EfficientNetEncoder(nn.Module):
+    """smp EfficientNetEncoder.get_stages / forward: [identity, stem + bn0 + swish, blocks[:i0], [i0:i1], [i1:i2], [i2:]], the drop_connect
+    rate of block b = 0.2 * b / len(blocks)."""
+
+    def __init__(self, name, in_channels=3, depth=5):
+        super().__init__()
+        cfg, bl = _EFFNET_CFG[name], effnet_block_list(name)
+        self._depth = depth
+        self._stage_idxs = cfg['stage_idxs']
+        self.out_channels = ENCODER_CHANNELS[name][:depth + 1]
+        bn = dict(momentum=0.01, eps=1e-3)
+        self._conv_stem = StaticSamePadConv2d(in_channels, bl['stem'], 3, 2, pad=bl['stem_pad'])
+        self._bn0 = nn.BatchNorm2d(bl['stem'], **bn)
+        self._blocks = nn.ModuleList([MBConvBlock(*b) for b in bl['blocks']])
+        self._conv_head = StaticSamePadConv2d(bl['blocks'][-1][4], bl['head'], 1)     # (kept by smp, never run)
+        self._bn1 = nn.BatchNorm2d(bl['head'], **bn)
+        self.drop_connect_rate = 0.2
+
+    def forward(self, x):
+        feats = [x]
+        x = F.silu(self._bn0(self._conv_stem(x))); feats.append(x)
+        lo, n = 0, float(len(self._blocks))
+        for i in range(2, self._depth + 1):
+            hi = self._stage_idxs[i - 2] if i - 2 < 3 else len(self._blocks)
+            for b in range(lo, hi):
+                x = self._blocks[b](x, self.drop_connect_rate * b / n)
+            lo = hi
+            feats.append(x)
+        return feats
+
+
 class Conv2dReLU(nn.Sequential):
     def __init__(self, cin, cout, kernel_size, padding=0):
         super().__init__(
@@ -661,7 +799,11 @@ def _init_head(module):
 class SegmentationModel(nn.Module):
     def __init__(self, arch, encoder_name, in_channels, classes):
         super().__init__()
-        if encoder_name in _REGNET_CFG:
+        if encoder_name in _EFFNET_CFG:
+            if arch in ('deeplabv3', 'deeplabv3plus'):
+                raise ValueError('the dilated (make_dilated) EfficientNet encoders are not restated (smp raises for them as well)')
+            self.encoder = EfficientNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)
+        elif encoder_name in _REGNET_CFG:
             if arch in ('deeplabv3', 'deeplabv3plus'):
                 raise ValueError('the dilated (make_dilated) RegNet encoders are not restated')
             self.encoder = RegNetEncoder(encoder_name, in_channels, depth=3 if arch == 'pspnet' else 5)

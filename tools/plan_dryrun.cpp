@@ -43,6 +43,8 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
   const int dls = !strcmp(d.arch, "deeplabv3plus") ? 16 : !strcmp(d.arch, "deeplabv3") ? 8 : 0;   // element-wise [B][H/s][W/s][256]; fpn [B][128], pspnet [B][512]
   float* keep = (float*)carve(dls ? (size_t)d.batch * (d.height / dls) * (d.width / dls) * 256 * 4 : (size_t)d.batch * 512 * 4);
   octseg_plan_set_dropout(p, keep);                 // (ignored by the other architectures)
+  float* dcf = (float*)carve((size_t)(octseg_plan_num_drop_connect(p) + 1) * d.batch * 4);
+  octseg_plan_set_drop_connect(p, dcf);             // EfficientNet encoders: drop_connect factors of the id skips
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   void* st = (void*)(uintptr_t)0x4000; void* comm = (void*)(uintptr_t)0x4100;
   const unsigned long long l0 = dry_launches();
@@ -83,7 +85,8 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 
 int main() {
   const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3"};
-  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064", "timm-regnety_120"};
+  const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064", "timm-regnety_120",
+                        "efficientnet-b0", "efficientnet-b5", "efficientnet-b7"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
   int plans = 0, executed = 0;
   unsigned long long checksum = 0;
@@ -93,9 +96,20 @@ int main() {
         for (int dtype = 0; dtype < 3; ++dtype)
           for (int classes : {1, 4}) {
             if (classes == 4 && !(sh[1] == 96 || dtype == 1)) continue;   // (the class count only changes the head: a subset is enough)
-            // timm RegNet encoders (grouped convs as per-group layers on channel slices): the engine builds them under U-Net, U-Net++ and
-            // FPN; LinkNet / PSPNet (quarter-width decoder convs: 92, 14 ... channels) and the dilated DeepLab encoders are refused (below)
-            if (!strncmp(enc, "timm-", 5) && (!strncmp(arch, "deeplab", 7) || (strcmp(enc, "timm-regnety_120") && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet"))))) continue;
+            // Encoders outside the ResNets (timm RegNet: grouped convs as per-group layers on channel slices; EfficientNet: MBConv blocks):
+            // built under U-Net, U-Net++ and FPN always; LinkNet / PSPNet only where a QUARTER of the feature widths is a multiple of the
+            // 8-channel vector (RegNetY-120 both, EfficientNet-B5 PSPNet); the dilated DeepLab encoders never.  The builder refuses the rest
+            // with OCTSEG_UNSUPPORTED_ARCH (checked here for every refused pair).
+            const bool other_enc = !strncmp(enc, "timm-", 5) || !strncmp(enc, "efficientnet-", 13);
+            if (other_enc && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet") || !strncmp(arch, "deeplab", 7))) {
+              const bool ok_pair = (!strcmp(enc, "timm-regnety_120") && strncmp(arch, "deeplab", 7)) || (!strcmp(enc, "efficientnet-b5") && !strcmp(arch, "pspnet"));
+              if (!ok_pair) {
+                octseg_net_desc dr{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
+                octseg_plan* pr = nullptr;
+                if (octseg_plan_create(&dr, &pr) != OCTSEG_UNSUPPORTED_ARCH || pr) { fprintf(stderr, "%s over %s was not refused\n", arch, enc); return 7; }
+                continue;
+              }
+            }
             octseg_net_desc d{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
             octseg_plan* p = nullptr;
             if (octseg_plan_create(&d, &p) != 0 || !p) {
