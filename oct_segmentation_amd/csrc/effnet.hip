@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void sefc_fwd_kernel(const SefcArgs a) {
     const float* w = a.w1 + (size_t)j * a.C;
     for (int c = 0; c < a.C; ++c) h = fmaf(w[c], m[c], h);
     a.h[n * a.R + j] = h;
-    act[j] = h * ef_sigmoid(h);
+    act[j] = a.act ? h * ef_sigmoid(h) : fmaxf(h, 0.f);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < a.C; c += 256) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void sefc_bwd_kernel(const SefcArgs a) {
     float d = 0.f;
     for (int c = 0; c < a.C; ++c) d = fmaf(a.w2[(size_t)c * a.R + j], ds[c], d);
     const float h = a.h[n * a.R + j], sg = ef_sigmoid(h);
-    d *= sg * (1.0f + h * (1.0f - sg));
+    d *= a.act ? sg * (1.0f + h * (1.0f - sg)) : (h > 0.f ? 1.f : 0.f);
     dh[j] = d;
     a.dh[n * a.R + j] = d;
   }
@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256) void sefc_wgrad_kernel(const SefcArgs a) {
     float acc = 0.f;
     if (e < CR) {                       // dW2[c][j]
       const int c = e / a.R, j = e - c * a.R;
-      for (int n = 0; n < a.N; ++n) { const float h = a.h[(size_t)n * a.R + j]; acc = fmaf(ef_ld1<T>(a.ds, (size_t)n * a.C + c), h * ef_sigmoid(h), acc); }
+      for (int n = 0; n < a.N; ++n) {
+        const float h = a.h[(size_t)n * a.R + j];
+        acc = fmaf(ef_ld1<T>(a.ds, (size_t)n * a.C + c), a.act ? h * ef_sigmoid(h) : fmaxf(h, 0.f), acc);
+      }
       a.dw2[e] += acc;
     } else if (e < 2 * CR) {            // dW1[j][c]
       const int k = e - CR, j = k / a.C, c = k - j * a.C;

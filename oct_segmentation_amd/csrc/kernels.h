@@ -57,6 +57,17 @@ int thin_stem_rows(int N, int H, int W);
 hipError_t launch_thin_stem_forward(int dtype, const StemArgs& s, hipStream_t st);
 hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
+// pab.hip: the position attention block of smp's MAnet decoder between its convolutions (strided f32-accumulating GEMMs on activations,
+// softmax over a whole position map, the un-transposed reshape of the attended map)
+struct PabGemm {           // C[b][m][n] (+)= sum_k A[b][m][k] B[b][k][n]; strides in elements; *_f32: the operand is float whatever the plan's dtype
+  const void* A; const void* B; void* C;
+  size_t sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn;
+  int M, N, K, batch, a_f32, b_f32, c_f32, accum;
+};
+hipError_t launch_pab_gemm(int dtype, const PabGemm& g, hipStream_t st);
+hipError_t launch_pab_softmax(float* S, const float* P, int batch, size_t n, int backward, hipStream_t st);   // forward: in place; backward: dP -> dS in place
+hipError_t launch_pab_mix(int dtype, const void* x, const float* M, void* y, float* dM, const void* dy, int N, int HW, int C, hipStream_t st);
+
 // effnet.hip: the non-GEMM operators of efficientnet_pytorch's MBConvBlock (smp 'efficientnet-b0' / '-b5' / '-b7')
 struct DwgArgs {           // depthwise K x K (3 | 5), stride 1 | 2, top/left padding `pad` (TF static "same"); w / dw: fp32 [K][K][C]
   const void* in; void* out; void* gin; const float* w; float* dw;   // backward: out = gout, gin = gradient of `in`
@@ -76,15 +87,18 @@ struct SefcArgs {          // s = W2 swish(W1 m + b1) + b2 on pooled vectors m [
   const float* w1; const float* b1; const float* w2; const float* b2; float* dw1; float* db1; float* dw2; float* db2;
   float* h; float* dh;
   int N, C, R;
+  int act;                 // activation between the two layers: 1 swish (EfficientNet), 0 ReLU (MAnet's SE_ll / SE_hl)
 };
 hipError_t launch_sefc_fwd(int dtype, const SefcArgs& a, hipStream_t st);
 hipError_t launch_sefc_bwd(int dtype, const SefcArgs& a, hipStream_t st);   // dm, dh, then the four parameter gradients (accumulated)
 
 // se.hip: squeeze-excite gate of timm's SEModule (RegNetY): out (+)= in * sigmoid(s[n][c]) and the gate's own gradient
 // ds[n][c] = sigmoid'(s) * sum_p g * x (float scratch `part`: N x se_dgate_shares(HW) x C floats)
-hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st);
+// (s2 / ds2 != nullptr: MAnet's MFAB gate sigmoid(s) + sigmoid(s2) -- two excitations of one tensor)
+hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st, const void* s2 = nullptr);
 int se_dgate_shares(int HW);
-hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* s, void* ds, float* part, int N, int HW, int C, hipStream_t st);
+hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* s, void* ds, float* part, int N, int HW, int C, hipStream_t st,
+                           const void* s2 = nullptr, void* ds2 = nullptr);
 
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);

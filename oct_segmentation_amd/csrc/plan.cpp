@@ -450,6 +450,38 @@ struct Builder {
     return o;
   }
   static Value mat_(int t) { Value v; v.t = t; v.bn = -1; return v; }
+  // ---- MAnet pieces (smp decoders/manet, restated in oracle/nets.py; kernels in pab.hip / se.hip / effnet.hip's sefc)
+  // nn.Sequential(AdaptiveAvgPool2d(1), Conv2d(C, rd, 1), ReLU, Conv2d(rd, C, 1), Sigmoid) up to the sigmoid: the excitation s [N][1][1][C]
+  int se_relu(const std::string& name, int in, int rd) {
+    const TensorInfo t = P->tensors[in];
+    const int g = gap(in);
+    const int s = tensor(t.N, 1, 1, t.C);
+    Op f; f.kind = OP_SEFC; f.in = g; f.out = s; f.up = rd; f.oc0 = 0;
+    f.ins[0] = param(name + ".1.weight", OCTSEG_P_CONV, 1, 1, rd, t.C, 0);
+    f.ins[1] = param(name + ".1.bias", OCTSEG_P_VEC, 1, 1, rd, 1, 0);
+    f.ins[2] = param(name + ".3.weight", OCTSEG_P_CONV, 1, 1, t.C, rd, 0);
+    f.ins[3] = param(name + ".3.bias", OCTSEG_P_VEC, 1, 1, t.C, 1, 0);
+    P->ops.push_back(f);
+    return s;
+  }
+  int gate2(int in, int s1, int s2) {    // in * (sigmoid(s1) + sigmoid(s2))
+    const TensorInfo t = P->tensors[in];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_SEGATE; op.in = in; op.ins[0] = s1; op.ins[1] = s2; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  int pab(const std::string& name, int x) {
+    const TensorInfo t = P->tensors[x];
+    const Value top = conv(name + ".top_conv", {{mat_(x), 0}}, 64, 1, 1, 0, "", true);
+    const Value center = conv(name + ".center_conv", {{mat_(x), 0}}, 64, 1, 1, 0, "", true);
+    const Value bottom = conv(name + ".bottom_conv", {{mat_(x), 0}}, t.C, 3, 1, 1, "", true);
+    const int y = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_PAB; op.in = x; op.ins[0] = top.t; op.ins[1] = center.t; op.ins[2] = bottom.t; op.out = y;
+    P->ops.push_back(op);
+    P->fwd_macs += (double)t.N * t.H * t.W * t.H * t.W * (64.0 + t.C);
+    return conv(name + ".out_conv", {{mat_(y), 0}}, t.C, 3, 1, 1, "", true).t;
+  }
   // ---- EfficientNet pieces (efficientnet_pytorch MBConvBlock, restated in oracle/nets.py; kernels in effnet.hip)
   void set_bn_effnet(int bi) { P->bns[bi].eps = 1e-3f; P->bns[bi].momentum = 0.01f; }
   // out = act(bn(y)) * drop_connect + post, materialised (swish has no lazy form in the conv kernels' staging)
@@ -480,7 +512,7 @@ struct Builder {
     const TensorInfo t = P->tensors[in];
     const int g = gap(in);
     const int s = tensor(t.N, 1, 1, t.C);
-    Op f; f.kind = OP_SEFC; f.in = g; f.out = s; f.up = rd;
+    Op f; f.kind = OP_SEFC; f.in = g; f.out = s; f.up = rd; f.oc0 = 1;
     f.ins[0] = param(pre + "._se_reduce.weight", OCTSEG_P_CONV, 1, 1, rd, t.C, 0);
     f.ins[1] = param(pre + "._se_reduce.bias", OCTSEG_P_VEC, 1, 1, rd, 1, 0);
     f.ins[2] = param(pre + "._se_expand.weight", OCTSEG_P_CONV, 1, 1, t.C, rd, 0);
@@ -854,6 +886,27 @@ static int build_plan(octseg_plan* P) {
       }
     }
     x = unet_block(b, "decoder.blocks." + key(0, depth), dense[key(0, depth - 1)], {}, dec[4]);
+  } else if (P->arch == "manet") {
+    // smp MAnet (reference sweep, configs/tune.yaml:17) at its defaults: PAB on the deepest feature, MFAB blocks (SE gates on the upsampled
+    // high-level path and on the skip, summed) where there is a skip, a plain U-Net block for the last one; 3x3 head on 16 channels
+    x = mat(b.pab("decoder.center", fr[0]));
+    for (int i = 0; i < 5; ++i) {
+      const std::string pre = "decoder.blocks." + std::to_string(i);
+      const int in_ch = i == 0 ? ench[0] : dec[i - 1];
+      if (i < 4) {
+        const int skip = fr[i + 1], skip_ch = ench[i + 1];
+        Value v1 = b.conv(pre + ".hl_conv.0.0", {{x, 0}}, in_ch, 3, 1, 1, pre + ".hl_conv.0.1", false);
+        Value v2 = b.conv(pre + ".hl_conv.1.0", {{v1, 0}}, skip_ch, 1, 1, 0, pre + ".hl_conv.1.1", false);
+        const int hl = b.bn_act(v2, Value(), -1, true);
+        const int rd = std::max(1, skip_ch / 16);
+        const int s_ll = b.se_relu(pre + ".SE_ll", skip, rd);          // (parameter order of the module: SE_ll before SE_hl)
+        const int s_hl = b.se_relu(pre + ".SE_hl", hl, rd);            // mean of the nearest-x2 upsampled map = mean of the map
+        const int gated = b.gate2(hl, s_hl, s_ll);                      // the gate is per (image, channel): applied BEFORE the upsample
+        x = unet_block(b, pre, mat(gated), {mat(skip)}, dec[i]);
+      } else {
+        x = unet_block(b, pre, x, {}, dec[i]);
+      }
+    }
   } else if (P->arch == "linknet") {
     head_k = 1;
     std::vector<int> ch = ench;
@@ -991,12 +1044,12 @@ static int build_plan(octseg_plan* P) {
     b.dw(hm, t2, 256, wp2, 256, 1);
     x = b.conv("decoder.block2.0.1", {{mat(t2), 0}}, 256, 1, 1, 0, "decoder.block2.1", false);
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | deeplabv3 | pspnet)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | deeplabv3 | pspnet | manet)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (!regnet && !effnet && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
+  if (!regnet && !effnet && P->arch != "manet" && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -1131,6 +1184,11 @@ static int build_plan(octseg_plan* P) {
     P->se_part_off = off; off += align_up(se_part);
     for (auto& op : P->ops)
       if (op.kind == OP_SEFC) { const TensorInfo& t = P->tensors[op.in]; op.aux_off = off; off += align_up((size_t)2 * t.N * op.up * sizeof(float)); }
+      else if (op.kind == OP_PAB) {
+        const TensorInfo& t = P->tensors[op.in];
+        const size_t hw = (size_t)t.H * t.W;
+        op.aux_off = off; off += align_up((size_t)t.N * hw * hw * sizeof(float)) * 2 + align_up((size_t)t.N * hw * t.C * sizeof(float));
+      }
   }
   P->dlogits_off = off; off += align_up((size_t)P->B * P->H * P->W * P->dlogits_C * esz);
   P->dice_off = off; off += align_up((size_t)(1 + P->B) * P->classes * DICE_NS * sizeof(double));   // totals + per-image replicas
@@ -1479,7 +1537,30 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
       }
       case OP_SEGATE: {
         const TensorInfo& t = P->tensors[op.in];
-        HIPCHK(launch_se_gate(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), t.N, t.H * t.W, t.C, 0, st));
+        HIPCHK(launch_se_gate(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), t.N, t.H * t.W, t.C, 0, st,
+                              op.ins[1] >= 0 ? E.act(op.ins[1]) : nullptr));
+        break;
+      }
+      case OP_PAB: {
+        const TensorInfo& t = P->tensors[op.in];
+        const int hw = t.H * t.W;
+        float* S = (float*)(E.ws + op.aux_off);
+        float* M = (float*)(E.ws + op.aux_off + 2 * align_up((size_t)t.N * hw * hw * sizeof(float)));
+        PabGemm g;
+        memset(&g, 0, sizeof(g));
+        g.batch = t.N;
+        // S[i][j] = sum_k center[i][k] top[j][k]
+        g.A = E.act(op.ins[1]); g.sAb = (size_t)hw * 64; g.sAm = 64; g.sAk = 1;
+        g.B = E.act(op.ins[0]); g.sBb = (size_t)hw * 64; g.sBk = 1; g.sBn = 64;
+        g.C = S; g.sCb = (size_t)hw * hw; g.sCm = hw; g.sCn = 1; g.c_f32 = 1; g.M = hw; g.N = hw; g.K = 64;
+        HIPCHK(launch_pab_gemm(P->dtype, g, st));
+        HIPCHK(launch_pab_softmax(S, nullptr, t.N, (size_t)hw * hw, 0, st));
+        // M[i][c] = sum_j P[i][j] bottom[j][c]
+        g.A = S; g.a_f32 = 1; g.sAb = (size_t)hw * hw; g.sAm = hw; g.sAk = 1;
+        g.B = E.act(op.ins[2]); g.b_f32 = 0; g.sBb = (size_t)hw * t.C; g.sBk = t.C; g.sBn = 1;
+        g.C = M; g.sCb = (size_t)hw * t.C; g.sCm = t.C; g.sCn = 1; g.M = hw; g.N = t.C; g.K = hw;
+        HIPCHK(launch_pab_gemm(P->dtype, g, st));
+        HIPCHK(launch_pab_mix(P->dtype, E.act(op.in), M, E.act(op.out), nullptr, nullptr, t.N, hw, t.C, st));
         break;
       }
       case OP_DWG: {
@@ -1519,7 +1600,7 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         a.w1 = E.params + P->params[op.ins[0]].off; a.b1 = E.params + P->params[op.ins[1]].off;
         a.w2 = E.params + P->params[op.ins[2]].off; a.b2 = E.params + P->params[op.ins[3]].off;
         a.h = (float*)(E.ws + op.aux_off); a.dh = a.h + (size_t)t.N * op.up;
-        a.N = t.N; a.C = t.C; a.R = op.up;
+        a.N = t.N; a.C = t.C; a.R = op.up; a.act = op.oc0;
         HIPCHK(launch_sefc_fwd(P->dtype, a, st));
         break;
       }
@@ -1931,18 +2012,61 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         a.dw1 = E.grads + P->params[op.ins[0]].off; a.db1 = E.grads + P->params[op.ins[1]].off;
         a.dw2 = E.grads + P->params[op.ins[2]].off; a.db2 = E.grads + P->params[op.ins[3]].off;
         a.h = (float*)(E.ws + op.aux_off); a.dh = a.h + (size_t)t.N * op.up;
-        a.N = t.N; a.C = t.C; a.R = op.up;
+        a.N = t.N; a.C = t.C; a.R = op.up; a.act = op.oc0;
         HIPCHK(launch_sefc_bwd(P->dtype, a, E.st));
         E.ginit[op.in] = 1;
         break;
       }
       case OP_SEGATE: {     // d x (+)= g * sigmoid(s);  d s = sigmoid'(s) * sum_p g * x
         const TensorInfo& t = P->tensors[op.in];
+        const bool two = op.ins[1] >= 0;
         HIPCHK(launch_se_dgate(P->dtype, E.grad(op.out), E.act(op.in), E.act(op.ins[0]), E.grad(op.ins[0]), (float*)(E.ws + P->se_part_off), t.N, t.H * t.W,
-                               t.C, E.st));
+                               t.C, E.st, two ? E.act(op.ins[1]) : nullptr, two ? E.grad(op.ins[1]) : nullptr));
         E.ginit[op.ins[0]] = 1;
+        if (two) E.ginit[op.ins[1]] = 1;
         const int acc = E.claim(op.in);
-        HIPCHK(launch_se_gate(P->dtype, E.grad(op.out), E.act(op.ins[0]), E.grad(op.in), t.N, t.H * t.W, t.C, acc, E.st));
+        HIPCHK(launch_se_gate(P->dtype, E.grad(op.out), E.act(op.ins[0]), E.grad(op.in), t.N, t.H * t.W, t.C, acc, E.st, two ? E.act(op.ins[1]) : nullptr));
+        break;
+      }
+      case OP_PAB: {
+        const TensorInfo& t = P->tensors[op.in];
+        const int hw = t.H * t.W;
+        const size_t sbytes = align_up((size_t)t.N * hw * hw * sizeof(float));
+        float* Pm = (float*)(E.ws + op.aux_off);
+        float* dP = (float*)(E.ws + op.aux_off + sbytes);
+        float* dM = (float*)(E.ws + op.aux_off + 2 * sbytes);
+        // y = x + reshape(M): the gradient of y flows into x as it is, and into M through the same index map
+        {
+          const int acc = E.claim(op.in);
+          HIPCHK(launch_masked_accum(P->dtype, E.grad(op.in), E.grad(op.out), nullptr, (size_t)t.N * hw * t.C, acc ? 0 : 1, E.st));
+        }
+        HIPCHK(launch_pab_mix(P->dtype, nullptr, nullptr, nullptr, dM, E.grad(op.out), t.N, hw, t.C, E.st));
+        PabGemm g;
+        memset(&g, 0, sizeof(g));
+        g.batch = t.N;
+        // dP[i][j] = sum_c dM[i][c] bottom[j][c]
+        g.A = dM; g.a_f32 = 1; g.sAb = (size_t)hw * t.C; g.sAm = t.C; g.sAk = 1;
+        g.B = E.act(op.ins[2]); g.sBb = (size_t)hw * t.C; g.sBk = 1; g.sBn = t.C;
+        g.C = dP; g.c_f32 = 1; g.sCb = (size_t)hw * hw; g.sCm = hw; g.sCn = 1; g.M = hw; g.N = hw; g.K = t.C;
+        HIPCHK(launch_pab_gemm(P->dtype, g, E.st));
+        // d bottom[j][c] = sum_i P[i][j] dM[i][c]
+        g.A = Pm; g.a_f32 = 1; g.sAb = (size_t)hw * hw; g.sAm = 1; g.sAk = hw;
+        g.B = dM; g.b_f32 = 1; g.sBb = (size_t)hw * t.C; g.sBk = t.C; g.sBn = 1;
+        g.C = E.grad(op.ins[2]); g.c_f32 = 0; g.sCb = (size_t)hw * t.C; g.sCm = t.C; g.sCn = 1; g.M = hw; g.N = t.C; g.K = hw;
+        HIPCHK(launch_pab_gemm(P->dtype, g, E.st));
+        E.ginit[op.ins[2]] = 1;
+        HIPCHK(launch_pab_softmax(dP, Pm, t.N, (size_t)hw * hw, 1, E.st));     // dP -> dS in place
+        // d center[i][k] = sum_j dS[i][j] top[j][k];   d top[j][k] = sum_i dS[i][j] center[i][k]
+        g.A = dP; g.a_f32 = 1; g.sAb = (size_t)hw * hw; g.sAm = hw; g.sAk = 1;
+        g.B = E.act(op.ins[0]); g.b_f32 = 0; g.sBb = (size_t)hw * 64; g.sBk = 64; g.sBn = 1;
+        g.C = E.grad(op.ins[1]); g.sCb = (size_t)hw * 64; g.sCm = 64; g.sCn = 1; g.M = hw; g.N = 64; g.K = hw;
+        HIPCHK(launch_pab_gemm(P->dtype, g, E.st));
+        E.ginit[op.ins[1]] = 1;
+        g.sAm = 1; g.sAk = hw;
+        g.B = E.act(op.ins[1]);
+        g.C = E.grad(op.ins[0]);
+        HIPCHK(launch_pab_gemm(P->dtype, g, E.st));
+        E.ginit[op.ins[0]] = 1;
         break;
       }
       case OP_MOSAIC: {     // the inverse re-arrangement of the gradient (gutters of a mosaic gradient are zero)

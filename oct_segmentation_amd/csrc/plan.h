@@ -99,7 +99,8 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               // EfficientNet (effnet.hip)
               OP_DWG,        // out = depthwise K x K (wc0) stride `up` conv of in, top/left padding oc0, weights param dwp [K][K][C]
               OP_BNX,        // out = act(bn(y)) * drop_connect[n] + post: act = up (0 identity, 1 swish), drop-connect block oc0 (-1: none)
-              OP_SEFC };     // out [N][1][1][C] = W2 swish(W1 in + b1) + b2: params ins[0..3] = w1, b1, w2, b2; up = reduction channels
+              OP_SEFC,       // out [N][1][1][C] = W2 act(W1 in + b1) + b2: params ins[0..3] = w1, b1, w2, b2; up = reduction channels; oc0 = act (1 swish, 0 ReLU)
+              OP_PAB };      // MAnet's position attention: out = in + reshape(softmax(center topT) bottom); ins[0..2] = top, center, bottom (pab.hip)
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -114,7 +115,7 @@ struct Op {
   int ins[4] = {-1, -1, -1, -1};   // OP_MERGE
   int dwp = -1, oc0 = 0, wc0 = 0;  // OP_DW: weight parameter, first output channel, first weight channel
   bool dw_first = true;            // OP_DW: first writer of the parameter's gradient slice? (all slices accumulate: atomics)
-  size_t aux_off = 0;              // OP_SEFC: float scratch h [N][R], dh [N][R] in the workspace
+  size_t aux_off = 0;              // OP_SEFC: float scratch h [N][R], dh [N][R] in the workspace; OP_PAB: S / P [N][HW^2], dP [N][HW^2], M [N][HW][C]
   bool conv_bn = false;            // OP_BNX: the BatchNorm is fed (and, in eval, folded) by a conv epilogue
 };
 

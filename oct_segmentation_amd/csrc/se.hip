@@ -28,7 +28,7 @@ static __device__ __forceinline__ float se_sigmoid(float z) {
 
 // out (+)= in * sigmoid(s[n][c])
 template <typename T>
-__global__ __launch_bounds__(256) void se_gate_kernel(const void* in, const void* s, void* out, size_t HW, int vpc, int accum, size_t nvec) {
+__global__ __launch_bounds__(256) void se_gate_kernel(const void* in, const void* s, void* out, size_t HW, int vpc, int accum, size_t nvec, const void* s2) {
   constexpr int VEC = EV<T>::VEC;
   for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
     const int cv = (int)(v % vpc);
@@ -37,7 +37,15 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const void* in, const void
     EV<T>::unpack(ldv<T>(in, v), f);
     EV<T>::unpack(ldv<T>(s, n * vpc + cv), g);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) f[i] *= se_sigmoid(g[i]);
+    for (int i = 0; i < VEC; ++i) g[i] = se_sigmoid(g[i]);
+    if (s2 != nullptr) {       // MAnet's MFAB: attention_hl + attention_ll, each behind its own sigmoid
+      float g2[VEC];
+      EV<T>::unpack(ldv<T>(s2, n * vpc + cv), g2);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] += se_sigmoid(g2[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] *= g[i];
     if (accum) {
       float o[VEC];
       EV<T>::unpack(ldv<T>(out, v), o);
@@ -47,11 +55,11 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const void* in, const void
     stv<T>(out, v, EV<T>::pack(f));
   }
 }
-hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st) {
+hipError_t launch_se_gate(int dtype, const void* in, const void* s, void* out, int N, int HW, int C, int accum, hipStream_t st, const void* s2) {
   const int vec = dtype == DT_F32 ? 4 : 8;
   if (C % vec != 0) return hipErrorInvalidValue;
   const size_t nvec = (size_t)N * HW * (C / vec);
-  SE_DISPATCH(se_gate_kernel, dim3(grid_for(nvec, 256)), in, s, out, (size_t)HW, C / vec, accum, nvec);
+  SE_DISPATCH(se_gate_kernel, dim3(grid_for(nvec, 256)), in, s, out, (size_t)HW, C / vec, accum, nvec, s2);
   return hipGetLastError();
 }
 
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void se_dgate_part_kernel(const void* g, const
 }
 // ds[n][c] = sigmoid'(s[n][c]) * sum over the shares (in share order)
 template <typename T>
-__global__ __launch_bounds__(256) void se_dgate_fin_kernel(const float* part, const void* s, void* ds, int shares, int vpc, int nvec) {
+__global__ __launch_bounds__(256) void se_dgate_fin_kernel(const float* part, const void* s, void* ds, int shares, int vpc, int nvec, const void* s2, void* ds2) {
   constexpr int VEC = EV<T>::VEC;
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
     const int n = v / vpc, cv = v - n * vpc;
@@ -104,16 +112,24 @@ __global__ __launch_bounds__(256) void se_dgate_fin_kernel(const float* part, co
       for (int i = 0; i < VEC; ++i) acc[i] += p[i];
     }
     EV<T>::unpack(ldv<T>(s, v), z);
+    float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { const float q = se_sigmoid(z[i]); acc[i] *= q * (1.0f - q); }
-    stv<T>(ds, v, EV<T>::pack(acc));
+    for (int i = 0; i < VEC; ++i) { const float q = se_sigmoid(z[i]); o[i] = acc[i] * q * (1.0f - q); }
+    stv<T>(ds, v, EV<T>::pack(o));
+    if (s2 != nullptr) {       // the second excitation of a two-gate sum sees the same sum of g * x
+      EV<T>::unpack(ldv<T>(s2, v), z);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float q = se_sigmoid(z[i]); o[i] = acc[i] * q * (1.0f - q); }
+      stv<T>(ds2, v, EV<T>::pack(o));
+    }
   }
 }
 int se_dgate_shares(int HW) {        // pixel shares of the s-side reduction: >= 64 pixels each, at most 64 shares
   int k = HW / 64;
   return k < 1 ? 1 : (k > 64 ? 64 : k);
 }
-hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* s, void* ds, float* part, int N, int HW, int C, hipStream_t st) {
+hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* s, void* ds, float* part, int N, int HW, int C, hipStream_t st,
+                           const void* s2, void* ds2) {
   OCTSEG_NO_F16(dtype);
   const int vec = dtype == DT_F32 ? 4 : 8;
   if (C % vec != 0) return hipErrorInvalidValue;
@@ -121,8 +137,8 @@ hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* 
   if (dtype == DT_F32) hipLaunchKernelGGL(se_dgate_part_kernel<float>, dim3((vpc + SE_CH - 1) / SE_CH, shares, N), dim3(256), 0, st, g, x, part, HW, vpc);
   else hipLaunchKernelGGL(se_dgate_part_kernel<bf16_t>, dim3((vpc + SE_CH - 1) / SE_CH, shares, N), dim3(256), 0, st, g, x, part, HW, vpc);
   const int nvec = N * vpc;
-  if (dtype == DT_F32) hipLaunchKernelGGL(se_dgate_fin_kernel<float>, dim3(grid_for((size_t)nvec, 256)), dim3(256), 0, st, part, s, ds, shares, vpc, nvec);
-  else hipLaunchKernelGGL(se_dgate_fin_kernel<bf16_t>, dim3(grid_for((size_t)nvec, 256)), dim3(256), 0, st, part, s, ds, shares, vpc, nvec);
+  if (dtype == DT_F32) hipLaunchKernelGGL(se_dgate_fin_kernel<float>, dim3(grid_for((size_t)nvec, 256)), dim3(256), 0, st, part, s, ds, shares, vpc, nvec, s2, ds2);
+  else hipLaunchKernelGGL(se_dgate_fin_kernel<bf16_t>, dim3(grid_for((size_t)nvec, 256)), dim3(256), 0, st, part, s, ds, shares, vpc, nvec, s2, ds2);
   return hipGetLastError();
 }
 

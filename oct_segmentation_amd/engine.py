@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet')
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
@@ -172,7 +172,9 @@ class SegNet(nn.Module):
                      # smp.DeepLabV3Plus's own keywords, at their defaults (decoder_channels: see _ARCH_DEFAULTS)
                      'encoder_output_stride': 16, 'decoder_atrous_rates': (12, 24, 36),
                      # smp.PSPNet's own keywords, at their defaults (encoder_depth, upsampling: see _ARCH_DEFAULTS)
-                     'psp_out_channels': 512, 'psp_use_batchnorm': True, 'psp_dropout': 0.2}
+                     'psp_out_channels': 512, 'psp_use_batchnorm': True, 'psp_dropout': 0.2,
+                     # smp.MAnet's own keywords, at their defaults
+                     'decoder_pab_channels': 64}
     _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8},
                       'deeplabv3': {'decoder_channels': 256, 'upsampling': 8}}
 

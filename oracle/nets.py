@@ -493,6 +493,77 @@ class UnetPlusPlusDecoder(nn.Module):
         return dense[f'x_0_{self.depth}']
 
 
+
+# ------------------------------------------------------------------------------------------------ MAnet decoder
+# smp 0.3.3 ``decoders/manet/decoder.py`` (reference sweep: configs/tune.yaml:17 ``MAnet`` through smp.create_model, model.py:38-44) at its
+# defaults: decoder_channels (256, 128, 64, 32, 16), decoder_pab_channels 64, reduction 16, BatchNorm on.  Restated from the published source,
+# its two quirks included: PAB's softmax runs over ALL (HW)^2 entries of the position map at once (``view(bsize, -1)`` + Softmax(dim=1)), and
+# the attended map [B, HW, C] is ``reshape``d to [B, C, h, w] WITHOUT a transpose before it is added to the input.
+class PAB(nn.Module):
+    def __init__(self, in_channels, out_channels, pab_channels=64):
+        super().__init__()
+        self.pab_channels, self.in_channels = pab_channels, in_channels
+        self.top_conv = nn.Conv2d(in_channels, pab_channels, kernel_size=1)
+        self.center_conv = nn.Conv2d(in_channels, pab_channels, kernel_size=1)
+        self.bottom_conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1)
+        self.map_softmax = nn.Softmax(dim=1)
+        self.out_conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1)
+
+    def forward(self, x):
+        bsize, h, w = x.size(0), x.size(2), x.size(3)
+        x_top = self.top_conv(x).flatten(2)
+        x_center = self.center_conv(x).flatten(2).transpose(1, 2)
+        x_bottom = self.bottom_conv(x).flatten(2).transpose(1, 2)
+        sp_map = torch.matmul(x_center, x_top)
+        sp_map = self.map_softmax(sp_map.view(bsize, -1)).view(bsize, h * w, h * w)
+        sp_map = torch.matmul(sp_map, x_bottom)
+        sp_map = sp_map.reshape(bsize, self.in_channels, h, w)
+        return self.out_conv(x + sp_map)
+
+
+class MFAB(nn.Module):
+    def __init__(self, in_channels, skip_channels, out_channels, reduction=16):
+        super().__init__()
+        self.hl_conv = nn.Sequential(Conv2dReLU(in_channels, in_channels, 3, 1), Conv2dReLU(in_channels, skip_channels, 1))
+        rd = max(1, skip_channels // reduction)
+
+        def se():
+            return nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(skip_channels, rd, 1), nn.ReLU(inplace=True), nn.Conv2d(rd, skip_channels, 1), nn.Sigmoid())
+        self.SE_ll = se()
+        self.SE_hl = se()
+        self.conv1 = Conv2dReLU(skip_channels + skip_channels, out_channels, 3, 1)
+        self.conv2 = Conv2dReLU(out_channels, out_channels, 3, 1)
+
+    def forward(self, x, skip=None):
+        x = self.hl_conv(x)
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+        attention_hl = self.SE_hl(x)
+        if skip is not None:
+            attention_hl = attention_hl + self.SE_ll(skip)
+            x = x * attention_hl
+            x = torch.cat([x, skip], dim=1)
+        return self.conv2(self.conv1(x))
+
+
+class MAnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=(256, 128, 64, 32, 16), reduction=16, pab_channels=64):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        head = enc[0]
+        ins = [head] + list(decoder_channels[:-1])
+        skips = enc[1:] + [0]
+        self.center = PAB(head, head, pab_channels=pab_channels)
+        self.blocks = nn.ModuleList([MFAB(i, s, o, reduction) if s > 0 else UnetDecoderBlock(i, s, o) for i, s, o in zip(ins, skips, decoder_channels)])
+
+    def forward(self, *features):
+        features = features[1:][::-1]
+        x = self.center(features[0])
+        skips = features[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
 class TransposeX2(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(
@@ -816,6 +887,9 @@ class SegmentationModel(nn.Module):
         elif arch == 'unetplusplus':
             self.decoder = UnetPlusPlusDecoder(ch)
             self.segmentation_head = SegmentationHead(16, classes, 3)
+        elif arch == 'manet':
+            self.decoder = MAnetDecoder(ch)
+            self.segmentation_head = SegmentationHead(16, classes, 3)
         elif arch == 'linknet':
             self.decoder = LinknetDecoder(ch)
             self.segmentation_head = SegmentationHead(32, classes, 1)
@@ -850,7 +924,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):

@@ -84,7 +84,7 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 }  // namespace
 
 int main() {
-  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3"};
+  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3", "manet"};
   const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064", "timm-regnety_120",
                         "efficientnet-b0", "efficientnet-b5", "efficientnet-b7"};
   const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
@@ -163,7 +163,7 @@ int main() {
   octseg_net_desc badr1{"linknet", "timm-regnetx_002", 1, 1, 32, 32, 0}, badr2{"deeplabv3plus", "timm-regnetx_064", 1, 2, 64, 64, 1},
       badr3{"pspnet", "timm-regnetx_002", 1, 2, 64, 64, 0};
   if (octseg_plan_create(&badr1, &q) == 0 || octseg_plan_create(&badr2, &q) == 0 || octseg_plan_create(&badr3, &q) == 0) { fprintf(stderr, "an unsupported RegNet pair was accepted\n"); return 7; }
-  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"manet", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
+  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"pan", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
       bad4{"unet", "resnet18", 0, 1, 32, 32, 0}, bad5{"unet", "resnet18", 1, 1, 32, 32, 7};
   for (octseg_net_desc* b : {&bad1, &bad2, &bad3, &bad4, &bad5})
     if (octseg_plan_create(b, &q) == 0) { fprintf(stderr, "a bad descriptor was accepted\n"); return 7; }
