@@ -51,6 +51,7 @@ WORKLOADS = {
     'unet_effb0_704': ('unet', 'efficientnet-b0', 1, 704),           # efficientnet_pytorch encoders of the sweep (configs/tune.yaml:25-28)
     'fpn_effb5_704': ('fpn', 'efficientnet-b5', 1, 704),
     'manet_r50_704': ('manet', 'resnet50', 1, 704),                   # smp MAnet (configs/tune.yaml:17)
+    'pan_r50_704': ('pan', 'resnet50', 1, 704),                       # smp PAN (configs/tune.yaml:18)
 }
 
 

@@ -57,6 +57,27 @@ int thin_stem_rows(int N, int H, int W);
 hipError_t launch_thin_stem_forward(int dtype, const StemArgs& s, hipStream_t st);
 hipError_t launch_thin_stem_wgrad(int dtype, const StemArgs& s, hipStream_t st);
 
+// pan.hip: smp's PAN decoder beside its convs -- MaxPool2d(2, 2), the feature-pyramid-attention block's one-channel pyramid (one workgroup, f32),
+// its wide 7x7 -> 1-channel conv, the final u * mid + b1 mix, and a plain add
+hipError_t launch_maxpool2(int dtype, const void* x, void* p, const void* dp, void* dx, int N, int H, int W, int C, int accum, hipStream_t st);   // dp == nullptr: forward
+hipError_t launch_fpa_in_fwd(int dtype, const void* p, const float* w, const float* b, float* y, int N, int H, int W, int C, int K, hipStream_t st);
+hipError_t launch_fpa_in_bwd(int dtype, const void* p, const float* dy, const float* w, void* dp, float* dw, float* db, int N, int H, int W, int C, int K,
+                             hipStream_t st);
+struct FpaPyrArgs {        // layers 0..5 = down1, down2, down3.1, down3.2, conv2, conv1 (each conv k x k + bias, BatchNorm2d(1), ReLU)
+  int N, h, w, train;      // h x w: the block's input map; the pyramid lives on h/2, h/4, h/8
+  float* scratch; float* gscratch; const float* duu;
+  const float* w_[6]; const float* b_[6]; const float* g_[6]; const float* be_[6]; float* rm_[6]; float* rv_[6];
+  float* dw_[6]; float* db_[6]; float* dg_[6]; float* dbe_[6];
+};
+size_t fpa_pyr_scratch_floats(int N, int h, int w);    // forward values kept for the backward (+ the upsampled map uu [N][h][w] and 12 statistics)
+size_t fpa_pyr_gscratch_floats(int N, int h, int w);   // gradients; d(x1raw) ends at gscratch + N (h/2) (w/2)
+hipError_t launch_fpa_pyr_fwd(const FpaPyrArgs& a, hipStream_t st);   // x1raw in scratch[0 .. n1) -> uu at scratch + fpa_pyr_uu_offset
+hipError_t launch_fpa_pyr_bwd(const FpaPyrArgs& a, hipStream_t st);
+static inline size_t fpa_pyr_uu_offset(int N, int h, int w) { return fpa_pyr_scratch_floats(N, h, w) - 16 - (size_t)N * h * w; }
+hipError_t launch_fpa_mix(int dtype, const float* uu, const void* mid, const void* b1, void* out, const void* g, void* dmid, float* duu, int N, int HW, int C,
+                          hipStream_t st);             // g == nullptr: forward out = uu mid + b1; else dmid = g uu, duu = sum_c g mid
+hipError_t launch_add2(int dtype, const void* a, const void* b, void* out, size_t numel, hipStream_t st);
+
 // pab.hip: the position attention block of smp's MAnet decoder between its convolutions (strided f32-accumulating GEMMs on activations,
 // softmax over a whole position map, the un-transposed reshape of the attended map)
 struct PabGemm {           // C[b][m][n] (+)= sum_k A[b][m][k] B[b][k][n]; strides in elements; *_f32: the operand is float whatever the plan's dtype

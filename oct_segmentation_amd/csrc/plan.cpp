@@ -450,6 +450,47 @@ struct Builder {
     return o;
   }
   static Value mat_(int t) { Value v; v.t = t; v.bn = -1; return v; }
+  // ---- PAN pieces (smp decoders/pan, restated in oracle/nets.py; kernels in pan.hip)
+  int add2(int a, int c) {
+    const TensorInfo t = P->tensors[a];
+    const int o = tensor(t.N, t.H, t.W, t.C);
+    Op op; op.kind = OP_ADD; op.in = a; op.ins[0] = c; op.out = o;
+    P->ops.push_back(op);
+    return o;
+  }
+  // GAUBlock(x = low-level feature, y = high-level map): bilinear(y) + relu(bn(conv3x3(x))) * sigmoid(bn(conv1x1(mean(y))))
+  int gau(const std::string& pre, int x, int y) {
+    const TensorInfo tx = P->tensors[x];
+    const Value v2 = conv(pre + ".conv2.conv", {{mat_(x), 0}}, 32, 3, 1, 1, pre + ".conv2.bn", true);
+    const int xg = bn_act(v2, Value(), -1, true);
+    const Value v1 = conv(pre + ".conv1.1.conv", {{mat_(gap(y)), 0}}, 32, 1, 1, 0, pre + ".conv1.1.bn", true);
+    const int s = bn_act(v1, Value(), -1, false);
+    const int z = tensor(tx.N, tx.H, tx.W, 32);
+    { Op op; op.kind = OP_SEGATE; op.in = xg; op.ins[0] = s; op.out = z; P->ops.push_back(op); }
+    return add2(resize(y, tx.H, tx.W), z);
+  }
+  // FPABlock: global branch b1, 1x1 branch mid, the one-channel pyramid (pan.hip), out = pyramid * mid + b1
+  int fpa(const std::string& pre, int x) {
+    const TensorInfo t = P->tensors[x];
+    const Value vb = conv(pre + ".branch1.1.conv", {{mat_(gap(x)), 0}}, 32, 1, 1, 0, pre + ".branch1.1.bn", true);
+    const int b1 = bn_act(vb, Value(), -1, true);
+    const Value vm = conv(pre + ".mid.0.conv", {{mat_(x), 0}}, 32, 1, 1, 0, pre + ".mid.0.bn", true);
+    const int mid = bn_act(vm, Value(), -1, true);
+    const char* names[6] = {".down1.1", ".down2.1", ".down3.1", ".down3.2", ".conv2", ".conv1"};
+    const int ks[6] = {7, 5, 3, 3, 5, 7};
+    for (int l = 0; l < 6; ++l) {
+      const std::string n = pre + names[l];
+      P->fpa.w[l] = param(n + ".conv.weight", OCTSEG_P_CONV, ks[l], ks[l], 1, l == 0 ? t.C : 1, 0);
+      P->fpa.b[l] = param(n + ".conv.bias", OCTSEG_P_VEC, 1, 1, 1, 1, 0);
+      P->fpa.bn[l] = bn(n + ".bn", 1, x, false);
+    }
+    P->fpa.pool = tensor(t.N, t.H / 2, t.W / 2, t.C);                 // MaxPool2d(2, 2) of the feature (the 7x7 conv's input)
+    const int o = tensor(t.N, t.H, t.W, 32);
+    Op op; op.kind = OP_FPA; op.in = x; op.ins[0] = mid; op.ins[1] = b1; op.out = o;
+    P->ops.push_back(op);
+    P->fwd_macs += (double)t.N * (t.H / 2) * (t.W / 2) * 49.0 * t.C;
+    return o;
+  }
   // ---- MAnet pieces (smp decoders/manet, restated in oracle/nets.py; kernels in pab.hip / se.hip / effnet.hip's sefc)
   // nn.Sequential(AdaptiveAvgPool2d(1), Conv2d(C, rd, 1), ReLU, Conv2d(rd, C, 1), Sigmoid) up to the sigmoid: the excitation s [N][1][1][C]
   int se_relu(const std::string& name, int in, int rd) {
@@ -837,6 +878,7 @@ static int build_plan(octseg_plan* P) {
   const bool regnet = regnet_cfg(P->encoder, rcfg);
   EffCfg ecfg;
   const bool effnet = effnet_cfg(P->encoder, ecfg);
+  if ((effnet || regnet) && P->arch == "pan") return fail(OCTSEG_UNSUPPORTED_ARCH, "PAN dilates its encoder (output stride 16): built over the ResNets");
   if (effnet) {
     if (P->arch == "deeplabv3plus" || dlv3) return fail(OCTSEG_UNSUPPORTED_ARCH, "EfficientNet encoders cannot be dilated (smp raises for DeepLabV3 / DeepLabV3+ over them too)");
     f = build_effnet(b, ecfg, P->arch == "pspnet" ? 3 : 5);
@@ -847,7 +889,7 @@ static int build_plan(octseg_plan* P) {
                   std::to_string(rcfg.w[P->arch == "pspnet" ? 1 : 3]) + " / 4 is not a multiple of the 8-channel vector the NHWC kernels move)");
     f = build_regnet(b, rcfg, P->arch == "pspnet" ? 3 : 5);
   } else {
-    f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus" || dlv3, P->arch == "pspnet" ? 3 : 5, dlv3);  // f[0]=f1 .. f[4]=f5
+    f = build_resnet(b, P->encoder, P->arch == "deeplabv3plus" || P->arch == "pan" || dlv3, P->arch == "pspnet" ? 3 : 5, dlv3);  // f[0]=f1 .. f[4]=f5
   }
   while (f.size() < 5) f.push_back(f.back());       // (PSPNet: three features; the slots of the others are never read)
   std::vector<int> fr(f.rbegin(), f.rend());          // features[1:][::-1]: f5, f4, f3, f2, f1
@@ -886,6 +928,19 @@ static int build_plan(octseg_plan* P) {
       }
     }
     x = unet_block(b, "decoder.blocks." + key(0, depth), dense[key(0, depth - 1)], {}, dec[4]);
+  } else if (P->arch == "pan") {
+    // smp PAN (reference sweep, configs/tune.yaml:18) at its defaults: encoder_output_stride 16 (layer4 dilated, as DeepLabV3+), decoder_channels
+    // 32, FPA on the last feature, three GAU blocks down to stride 4, 3x3 head + UpsamplingBilinear2d(4)
+    head_k = 3;
+    P->head_up = 4;
+    const TensorInfo t5 = P->tensors[f[4]];
+    // (frames below 128 x 128 leave nothing for the pyramid's third max-pool -- torch fails there too; the plan is still built, for its
+    //  parameter table, and refuses to run: run_forward)
+    if (t5.H < 8 || t5.W < 8) P->run_error = "PAN needs frames of at least 128 x 128 (its pyramid pools the stride-16 feature three times)";
+    const int x5 = b.fpa("decoder.fpa", f[4]);
+    const int x4 = b.gau("decoder.gau3", f[3], x5);
+    const int x3 = b.gau("decoder.gau2", f[2], x4);
+    x = mat(b.gau("decoder.gau1", f[1], x3));
   } else if (P->arch == "manet") {
     // smp MAnet (reference sweep, configs/tune.yaml:17) at its defaults: PAB on the deepest feature, MFAB blocks (SE gates on the upsampled
     // high-level path and on the skip, summed) where there is a skip, a plain U-Net block for the last one; 3x3 head on 16 channels
@@ -1044,12 +1099,12 @@ static int build_plan(octseg_plan* P) {
     b.dw(hm, t2, 256, wp2, 256, 1);
     x = b.conv("decoder.block2.0.1", {{mat(t2), 0}}, 256, 1, 1, 0, "decoder.block2.1", false);
   } else {
-    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | deeplabv3 | pspnet | manet)");
+    return fail(OCTSEG_UNSUPPORTED_ARCH, "unknown arch '" + P->arch + "' (unet | unetplusplus | linknet | fpn | deeplabv3plus | deeplabv3 | pspnet | manet | pan)");
   }
   b.conv("segmentation_head.0", {{x, 0}}, P->classes, head_k, 1, head_k / 2, "", true, false, true);
   if (P->head_up > 1) { Op op; op.kind = OP_UPLOGITS; P->ops.push_back(op); }
 
-  if (!regnet && !effnet && P->arch != "manet" && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
+  if (!regnet && !effnet && P->arch != "manet" && P->arch != "pan" && P->arch != "fpn" && P->arch != "deeplabv3plus" && P->arch != "pspnet" && P->arch != "deeplabv3") assign_lanes(P);
 
   // ---------------- workspace layout ----------------
   P->dlogits_C = 16;
@@ -1184,6 +1239,11 @@ static int build_plan(octseg_plan* P) {
     P->se_part_off = off; off += align_up(se_part);
     for (auto& op : P->ops)
       if (op.kind == OP_SEFC) { const TensorInfo& t = P->tensors[op.in]; op.aux_off = off; off += align_up((size_t)2 * t.N * op.up * sizeof(float)); }
+      else if (op.kind == OP_FPA) {
+        const TensorInfo& t = P->tensors[op.in];
+        P->fpa.scratch_off = off; off += align_up(fpa_pyr_scratch_floats(t.N, t.H, t.W) * sizeof(float));
+        P->fpa.gscratch_off = off; off += align_up((fpa_pyr_gscratch_floats(t.N, t.H, t.W) + (size_t)t.N * t.H * t.W) * sizeof(float));   // + d uu
+      }
       else if (op.kind == OP_PAB) {
         const TensorInfo& t = P->tensors[op.in];
         const size_t hw = (size_t)t.H * t.W;
@@ -1292,6 +1352,7 @@ static const void* fwd_weight(const Exec& E, const ConvLayer& L) { return E.ws +
 
 static int run_forward(Exec& E, const float* image, float* logits, int normalize, const float* mean, const float* stdv) {
   octseg_plan* P = E.P;
+  if (!P->run_error.empty()) return fail(OCTSEG_BAD_SHAPE, P->run_error);
   if (E.train)
     for (auto& b : P->bns)
       if (b.count <= 1.0) {   // torch.nn.functional.batch_norm raises the same way (reference runs it in training)
@@ -1539,6 +1600,31 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
         const TensorInfo& t = P->tensors[op.in];
         HIPCHK(launch_se_gate(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), t.N, t.H * t.W, t.C, 0, st,
                               op.ins[1] >= 0 ? E.act(op.ins[1]) : nullptr));
+        break;
+      }
+      case OP_ADD: {
+        const TensorInfo& t = P->tensors[op.out];
+        HIPCHK(launch_add2(P->dtype, E.act(op.in), E.act(op.ins[0]), E.act(op.out), (size_t)t.N * t.H * t.W * t.C, st));
+        break;
+      }
+      case OP_FPA: {
+        const TensorInfo& t = P->tensors[op.in];
+        float* scr = (float*)(E.ws + P->fpa.scratch_off);
+        HIPCHK(launch_maxpool2(P->dtype, E.act(op.in), E.act(P->fpa.pool), nullptr, nullptr, t.N, t.H, t.W, t.C, 0, st));
+        HIPCHK(launch_fpa_in_fwd(P->dtype, E.act(P->fpa.pool), E.params + P->params[P->fpa.w[0]].off, E.params + P->params[P->fpa.b[0]].off, scr, t.N, t.H / 2,
+                                 t.W / 2, t.C, 7, st));
+        FpaPyrArgs a;
+        memset(&a, 0, sizeof(a));
+        a.N = t.N; a.h = t.H; a.w = t.W; a.train = E.train; a.scratch = scr;
+        for (int l = 0; l < 6; ++l) {
+          const BNInfo& bn = P->bns[P->fpa.bn[l]];
+          a.w_[l] = E.params + P->params[P->fpa.w[l]].off; a.b_[l] = E.params + P->params[P->fpa.b[l]].off;
+          a.g_[l] = E.params + P->params[bn.gamma].off; a.be_[l] = E.params + P->params[bn.beta].off;
+          a.rm_[l] = E.buffers + bn.rm_off; a.rv_[l] = E.buffers + bn.rv_off;
+        }
+        HIPCHK(launch_fpa_pyr_fwd(a, st));
+        HIPCHK(launch_fpa_mix(P->dtype, scr + fpa_pyr_uu_offset(t.N, t.H, t.W), E.act(op.ins[0]), E.act(op.ins[1]), E.act(op.out), nullptr, nullptr, nullptr, t.N,
+                              t.H * t.W, 32, st));
         break;
       }
       case OP_PAB: {
@@ -2026,6 +2112,49 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
         if (two) E.ginit[op.ins[1]] = 1;
         const int acc = E.claim(op.in);
         HIPCHK(launch_se_gate(P->dtype, E.grad(op.out), E.act(op.ins[0]), E.grad(op.in), t.N, t.H * t.W, t.C, acc, E.st, two ? E.act(op.ins[1]) : nullptr));
+        break;
+      }
+      case OP_ADD: {
+        const TensorInfo& t = P->tensors[op.out];
+        const size_t n = (size_t)t.N * t.H * t.W * t.C;
+        for (int src : {op.in, op.ins[0]})
+          if (P->tensors[src].need_grad) {
+            const int acc = E.claim(src);
+            HIPCHK(launch_masked_accum(P->dtype, E.grad(src), E.grad(op.out), nullptr, n, acc ? 0 : 1, E.st));
+          }
+        break;
+      }
+      case OP_FPA: {
+        const TensorInfo& t = P->tensors[op.in];
+        const int n1 = t.N * (t.H / 2) * (t.W / 2);
+        float* scr = (float*)(E.ws + P->fpa.scratch_off);
+        float* gs = (float*)(E.ws + P->fpa.gscratch_off);
+        float* duu = gs + fpa_pyr_gscratch_floats(t.N, t.H, t.W);
+        // out = uu * mid + b1
+        HIPCHK(launch_fpa_mix(P->dtype, scr + fpa_pyr_uu_offset(t.N, t.H, t.W), E.act(op.ins[0]), nullptr, nullptr, E.grad(op.out), E.grad(op.ins[0]), duu, t.N,
+                              t.H * t.W, 32, E.st));
+        E.ginit[op.ins[0]] = 1;
+        HIPCHK(launch_image_sum(P->dtype, E.grad(op.out), E.grad(op.ins[1]), t.N, t.H * t.W, 32, 1.f, E.st));
+        E.ginit[op.ins[1]] = 1;
+        FpaPyrArgs a;
+        memset(&a, 0, sizeof(a));
+        a.N = t.N; a.h = t.H; a.w = t.W; a.train = 1; a.scratch = scr; a.gscratch = gs; a.duu = duu;
+        for (int l = 0; l < 6; ++l) {
+          const BNInfo& bn = P->bns[P->fpa.bn[l]];
+          a.w_[l] = E.params + P->params[P->fpa.w[l]].off; a.b_[l] = E.params + P->params[P->fpa.b[l]].off;
+          a.g_[l] = E.params + P->params[bn.gamma].off; a.be_[l] = E.params + P->params[bn.beta].off;
+          a.rm_[l] = E.buffers; a.rv_[l] = E.buffers;
+          a.dw_[l] = E.grads + P->params[P->fpa.w[l]].off; a.db_[l] = E.grads + P->params[P->fpa.b[l]].off;
+          a.dg_[l] = E.grads + P->params[bn.gamma].off; a.dbe_[l] = E.grads + P->params[bn.beta].off;
+        }
+        HIPCHK(launch_fpa_pyr_bwd(a, E.st));
+        // the wide 7x7 conv: d x1raw sits behind the first n1 floats of the gradient scratch; its input's gradient goes back through the max-pool
+        HIPCHK(launch_fpa_in_bwd(P->dtype, E.act(P->fpa.pool), gs + n1, E.params + P->params[P->fpa.w[0]].off, E.grad(P->fpa.pool),
+                                 E.grads + P->params[P->fpa.w[0]].off, E.grads + P->params[P->fpa.b[0]].off, t.N, t.H / 2, t.W / 2, t.C, 7, E.st));
+        {
+          const int acc = E.claim(op.in);
+          HIPCHK(launch_maxpool2(P->dtype, E.act(op.in), nullptr, E.grad(P->fpa.pool), E.grad(op.in), t.N, t.H, t.W, t.C, acc, E.st));
+        }
         break;
       }
       case OP_PAB: {

@@ -100,7 +100,10 @@ enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
               OP_DWG,        // out = depthwise K x K (wc0) stride `up` conv of in, top/left padding oc0, weights param dwp [K][K][C]
               OP_BNX,        // out = act(bn(y)) * drop_connect[n] + post: act = up (0 identity, 1 swish), drop-connect block oc0 (-1: none)
               OP_SEFC,       // out [N][1][1][C] = W2 act(W1 in + b1) + b2: params ins[0..3] = w1, b1, w2, b2; up = reduction channels; oc0 = act (1 swish, 0 ReLU)
-              OP_PAB };      // MAnet's position attention: out = in + reshape(softmax(center topT) bottom); ins[0..2] = top, center, bottom (pab.hip)
+              OP_PAB,        // MAnet's position attention: out = in + reshape(softmax(center topT) bottom); ins[0..2] = top, center, bottom (pab.hip)
+              // PAN (pan.hip)
+              OP_FPA,        // feature pyramid attention: out = pyramid(in) * ins[0] (mid) + ins[1] (b1); parameters in octseg_plan::fpa
+              OP_ADD };      // out = in + ins[0]
 struct Op {
   OpKind kind;
   int conv = -1;   // OP_CONV
@@ -151,6 +154,9 @@ struct octseg_plan {
   int stem_pad = 3;                          // top / left padding of the stem conv (3: ResNet 7x7, 1: RegNet 3x3, 0: EfficientNet's static 'same')
   const float* drop_connect = nullptr;       // EfficientNet: id-skip factors of the next training forward, device float [blocks with id skip][B]
   std::vector<float> dc_rates;               // their drop_connect rates (0.2 * block index / blocks)
+  std::string run_error;                     // non-empty: the plan exists (parameter table) but this frame size cannot run (PAN below 128 x 128)
+  struct { int w[6], b[6], bn[6]; int pool = -1; size_t scratch_off = 0, gscratch_off = 0; } fpa;   // PAN's FPA pyramid: parameter / BatchNorm indices of its six
+                                                                                                     // one-channel layers, the pooled-input tensor, f32 scratch
   size_t dlogits_off = 0;                    // NHWC padded dL/dlogits
   int loss_kind = 0;                         // LOSS_DICE | LOSS_BCE | LOSS_DICE_BCE (octseg_plan_set_loss)
   size_t dice_off = 0;                       // double sums[1 + B][C][DICE_NS]: totals, then one replica per image

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet', 'pan')
 _FPN_SEG_CHANNELS, _FPN_DROPOUT = 128, 0.2   # smp FPN defaults: decoder_segmentation_channels, decoder_dropout
 _DLV3P_CHANNELS, _DLV3P_DROPOUT = 256, 0.5  # smp DeepLabV3Plus: decoder_channels, the nn.Dropout(0.5) of ASPP.project (element-wise)
 _PSP_CHANNELS, _PSP_DROPOUT = 512, 0.2      # smp PSPNet: psp_out_channels, psp_dropout (Dropout2d)
@@ -175,7 +175,7 @@ class SegNet(nn.Module):
                      'psp_out_channels': 512, 'psp_use_batchnorm': True, 'psp_dropout': 0.2,
                      # smp.MAnet's own keywords, at their defaults
                      'decoder_pab_channels': 64}
-    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8},
+    _ARCH_DEFAULTS = {'deeplabv3plus': {'decoder_channels': 256}, 'pspnet': {'encoder_depth': 3, 'upsampling': 8}, 'pan': {'decoder_channels': 32},
                       'deeplabv3': {'decoder_channels': 256, 'upsampling': 8}}
 
     def __init__(self, arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1,

@@ -564,6 +564,78 @@ class MAnetDecoder(nn.Module):
         return x
 
 
+
+# ------------------------------------------------------------------------------------------------ PAN decoder
+# smp 0.3.3 ``decoders/pan`` (reference sweep: configs/tune.yaml:18 ``PAN`` through smp.create_model, model.py:38-44) at its defaults:
+# encoder_output_stride 16 (the ResNet's layer4 dilated), decoder_channels 32, bilinear upsampling with align_corners=True, 3x3 head +
+# UpsamplingBilinear2d(4).  Restated from the published source.
+class PanConvBnRelu(nn.Module):
+    def __init__(self, cin, cout, k, padding=0, add_relu=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, 1, padding, bias=True)
+        self.bn = nn.BatchNorm2d(cout)
+        self.add_relu = add_relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x) if self.add_relu else x
+
+
+class FPABlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.branch1 = nn.Sequential(nn.AdaptiveAvgPool2d(1), PanConvBnRelu(cin, cout, 1))
+        self.mid = nn.Sequential(PanConvBnRelu(cin, cout, 1))
+        self.down1 = nn.Sequential(nn.MaxPool2d(2, 2), PanConvBnRelu(cin, 1, 7, 3))
+        self.down2 = nn.Sequential(nn.MaxPool2d(2, 2), PanConvBnRelu(1, 1, 5, 2))
+        self.down3 = nn.Sequential(nn.MaxPool2d(2, 2), PanConvBnRelu(1, 1, 3, 1), PanConvBnRelu(1, 1, 3, 1))
+        self.conv2 = PanConvBnRelu(1, 1, 5, 2)
+        self.conv1 = PanConvBnRelu(1, 1, 7, 3)
+
+    def forward(self, x):
+        h, w = x.size(2), x.size(3)
+        up = dict(mode='bilinear', align_corners=True)
+        b1 = F.interpolate(self.branch1(x), size=(h, w), **up)
+        mid = self.mid(x)
+        x1 = self.down1(x)
+        x2 = self.down2(x1)
+        x3 = self.down3(x2)
+        x3 = F.interpolate(x3, size=(h // 4, w // 4), **up)
+        x = self.conv2(x2) + x3
+        x = F.interpolate(x, size=(h // 2, w // 2), **up)
+        x = x + self.conv1(x1)
+        x = F.interpolate(x, size=(h, w), **up)
+        return torch.mul(x, mid) + b1
+
+
+class GAUBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.AdaptiveAvgPool2d(1), PanConvBnRelu(cout, cout, 1, add_relu=False), nn.Sigmoid())
+        self.conv2 = PanConvBnRelu(cin, cout, 3, 1)
+
+    def forward(self, x, y):
+        h, w = x.size(2), x.size(3)
+        y_up = F.interpolate(y, size=(h, w), mode='bilinear', align_corners=True)
+        return y_up + torch.mul(self.conv2(x), self.conv1(y))
+
+
+class PANDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=32):
+        super().__init__()
+        self.out_channels = decoder_channels
+        self.fpa = FPABlock(encoder_channels[-1], decoder_channels)
+        self.gau3 = GAUBlock(encoder_channels[-2], decoder_channels)
+        self.gau2 = GAUBlock(encoder_channels[-3], decoder_channels)
+        self.gau1 = GAUBlock(encoder_channels[-4], decoder_channels)
+
+    def forward(self, *features):
+        x5 = self.fpa(features[-1])
+        x4 = self.gau3(features[-2], x5)
+        x3 = self.gau2(features[-3], x4)
+        return self.gau1(features[-4], x3)
+
+
 class TransposeX2(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(
@@ -887,6 +959,12 @@ class SegmentationModel(nn.Module):
         elif arch == 'unetplusplus':
             self.decoder = UnetPlusPlusDecoder(ch)
             self.segmentation_head = SegmentationHead(16, classes, 3)
+        elif arch == 'pan':
+            if not isinstance(self.encoder, ResNetEncoder):
+                raise ValueError('PAN dilates its encoder (output stride 16): restated for the ResNets')
+            self.encoder.make_dilated(16)
+            self.decoder = PANDecoder(ch)
+            self.segmentation_head = SegmentationHead(self.decoder.out_channels, classes, 3, upsampling=4)
         elif arch == 'manet':
             self.decoder = MAnetDecoder(ch)
             self.segmentation_head = SegmentationHead(16, classes, 3)
@@ -924,7 +1002,7 @@ class SegmentationModel(nn.Module):
         return self.segmentation_head(self.decoder(*self.encoder(x)))
 
 
-_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet')
+_ARCHS = ('unet', 'unetplusplus', 'linknet', 'fpn', 'deeplabv3plus', 'pspnet', 'deeplabv3', 'manet', 'pan')
 
 
 def create_model(arch, encoder_name='resnet34', encoder_weights=None, in_channels=3, classes=1, **kwargs):

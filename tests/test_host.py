@@ -220,4 +220,4 @@ def test_planner_and_executors_clean_under_asan_ubsan():
     r = subprocess.run([os.path.join(csrc, 'build', 'asan', 'plan_dryrun')], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-6000:]
-    assert '1206 plans built' in r.stdout    # 18 per pair: 8 archs x 5 ResNets, 4 x 2 RegNetX, 6 x RegNetY-120, 4 / 5 / 4 archs x EfficientNet-B0 / B5 / B7 and '0 errors' in r.stdout, r.stdout
+    assert '1296 plans built' in r.stdout    # 18 per pair: 9 archs x 5 ResNets, 4 x 2 RegNetX, 6 x RegNetY-120, 4 / 5 / 4 archs x EfficientNet-B0 / B5 / B7 and '0 errors' in r.stdout, r.stdout

@@ -84,10 +84,10 @@ int exercise(const octseg_net_desc& d, octseg_plan* p) {
 }  // namespace
 
 int main() {
-  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3", "manet"};
+  const char* archs[] = {"unet", "unetplusplus", "linknet", "fpn", "deeplabv3plus", "pspnet", "deeplabv3", "manet", "pan"};
   const char* encs[] = {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "timm-regnetx_002", "timm-regnetx_064", "timm-regnety_120",
                         "efficientnet-b0", "efficientnet-b5", "efficientnet-b7"};
-  const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};
+  const int shapes[][3] = {{1, 32, 32}, {16, 704, 704}, {3, 96, 64}, {2, 64, 160}};      // (PAN needs >= 128 x 128 to run: its frames are doubled below)
   int plans = 0, executed = 0;
   unsigned long long checksum = 0;
   for (const char* arch : archs)
@@ -101,6 +101,12 @@ int main() {
             // 8-channel vector (RegNetY-120 both, EfficientNet-B5 PSPNet); the dilated DeepLab encoders never.  The builder refuses the rest
             // with OCTSEG_UNSUPPORTED_ARCH (checked here for every refused pair).
             const bool other_enc = !strncmp(enc, "timm-", 5) || !strncmp(enc, "efficientnet-", 13);
+            if (other_enc && !strcmp(arch, "pan")) {        // PAN dilates its encoder: ResNets only
+              octseg_net_desc dr{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
+              octseg_plan* pr = nullptr;
+              if (octseg_plan_create(&dr, &pr) != OCTSEG_UNSUPPORTED_ARCH || pr) { fprintf(stderr, "pan over %s was not refused\n", enc); return 7; }
+              continue;
+            }
             if (other_enc && (!strcmp(arch, "linknet") || !strcmp(arch, "pspnet") || !strncmp(arch, "deeplab", 7))) {
               const bool ok_pair = (!strcmp(enc, "timm-regnety_120") && strncmp(arch, "deeplab", 7)) || (!strcmp(enc, "efficientnet-b5") && !strcmp(arch, "pspnet"));
               if (!ok_pair) {
@@ -110,7 +116,8 @@ int main() {
                 continue;
               }
             }
-            octseg_net_desc d{arch, enc, classes, sh[0], sh[1], sh[2], dtype};
+            const int fs = (!strcmp(arch, "pan") && sh[1] < 128) ? 2 : 1;
+            octseg_net_desc d{arch, enc, classes, sh[0], sh[1] * fs, sh[2] * fs, dtype};
             octseg_plan* p = nullptr;
             if (octseg_plan_create(&d, &p) != 0 || !p) {
               fprintf(stderr, "plan_create(%s, %s, B=%d %dx%d, dtype %d) failed: %s\n", arch, enc, sh[0], sh[1], sh[2], dtype, octseg_last_error());
@@ -163,7 +170,7 @@ int main() {
   octseg_net_desc badr1{"linknet", "timm-regnetx_002", 1, 1, 32, 32, 0}, badr2{"deeplabv3plus", "timm-regnetx_064", 1, 2, 64, 64, 1},
       badr3{"pspnet", "timm-regnetx_002", 1, 2, 64, 64, 0};
   if (octseg_plan_create(&badr1, &q) == 0 || octseg_plan_create(&badr2, &q) == 0 || octseg_plan_create(&badr3, &q) == 0) { fprintf(stderr, "an unsupported RegNet pair was accepted\n"); return 7; }
-  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"pan", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
+  octseg_net_desc bad1{"unet", "resnet18", 1, 1, 48, 64, 0}, bad2{"segformer", "resnet18", 1, 1, 32, 32, 0}, bad3{"unet", "vgg", 1, 1, 32, 32, 0},
       bad4{"unet", "resnet18", 0, 1, 32, 32, 0}, bad5{"unet", "resnet18", 1, 1, 32, 32, 7};
   for (octseg_net_desc* b : {&bad1, &bad2, &bad3, &bad4, &bad5})
     if (octseg_plan_create(b, &q) == 0) { fprintf(stderr, "a bad descriptor was accepted\n"); return 7; }
