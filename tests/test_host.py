@@ -76,9 +76,13 @@ def test_plan_argument_validation():
     lib = L.lib()
     rc, _ = _plan('unet', 'resnet18', 1, 1, 100, 100)
     assert rc == -1 and b'divisible by 32' in lib.octseg_last_error()   # smp check_input_shape text
-    rc, _ = _plan('manet', 'resnet18', 1, 1, 64, 64)       # (an smp architecture outside the built set)
+    rc, _ = _plan('segformer', 'resnet18', 1, 1, 64, 64)   # (not one of smp 0.3.3's nine architectures)
     assert rc == -3
-    for arch in ('fpn', 'deeplabv3plus', 'DeepLabV3Plus', 'PSPNet', 'DeepLabV3'):  # sweep architectures built since round 3 (case-insensitive like smp)
+    for enc in ('timm-regnetx_002', 'efficientnet-b0'):    # pairs the builder refuses: PAN dilates its encoder, LinkNet quarters the feature widths
+        for arch in ('pan', 'linknet', 'deeplabv3plus'):
+            rc, _ = _plan(arch, enc, 1, 1, 64, 64)
+            assert rc == -3, (arch, enc)
+    for arch in ('fpn', 'deeplabv3plus', 'DeepLabV3Plus', 'PSPNet', 'DeepLabV3', 'MAnet', 'PAN'):  # sweep architectures (case-insensitive like smp): round 3, MAnet / PAN round 4
         rc, pf = _plan(arch, 'resnet18', 1, 1, 64, 64)
         assert rc == 0
         lib.octseg_plan_destroy(pf)
