@@ -483,7 +483,7 @@ def main():
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3),
             'power': power,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + conv3x3p_kernel + gemm1x1_kernel + thin_conv_kernel + wgrad_mfma_kernel + thin_wgrad_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + conv3x3p_kernel + gemm1x1_kernel + thin_conv_kernel + wgrad_mfma_kernel + wgrad1x1_kernel + thin_wgrad_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),
@@ -515,7 +515,7 @@ def main():
         if args.force_exchange:
             out['config']['force_exchange'] = f'one-rank {args.backend} group: buffer broadcast + {args.allreduce_slices}-slice all-reduce issued beside the backward'
         # HBM traffic of the MFMA kernels from the TCC counters (tools/collect_traffic.py, separate rocprofv3 --pmc passes)
-        tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r{k}_traffic.json') for k in (3, 2, 1)) if os.path.exists(q)), '')
+        tpath = next((q for q in (os.path.join(ROOT, 'profiles', f'r{k}_traffic.json') for k in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), '')
         if os.path.exists(tpath) and args.workload == 'unetpp_r101_704' and B == 16 and args.dtype == 'bf16':
             try:
                 out['roofline']['traffic'] = round(json.load(open(tpath))['mfma_family']['hbm_bytes_per_launch'])

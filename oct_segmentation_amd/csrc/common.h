@@ -92,6 +92,7 @@ struct WgradArgs {
   int Cout;         // real number of output channels (rows of dW)
   float* dW;        // [wtaps][Cout][Cin] fp32, accumulated with atomics
   int ksplit;       // number of pixel-tile groups (grid.z)
+  int co_fast;      // set by the launcher: co tiles fastest in the XCD-local workgroup order (speed only)
   unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only
 };
 

@@ -446,8 +446,9 @@ __global__ __launch_bounds__(256) void bilinear_resize_adjoint_kernel(const void
   __shared__ float red[256 * VEC];
   const int v0 = blockIdx.x * DW_CH, nv = min(DW_CH, vpc - v0), rows = 256 / nv;
   const int r = threadIdx.x / nv, cv = threadIdx.x - r * nv;
-  const int pix = blockIdx.y % (IH * IW);
-  const size_t n = blockIdx.y / (IH * IW);
+  const size_t bidx = (size_t)blockIdx.z * gridDim.y + blockIdx.y;   // (source pixels beyond 65535 continue in grid.z: PAN's GAU maps)
+  const int pix = (int)(bidx % (size_t)(IH * IW));
+  const size_t n = bidx / (size_t)(IH * IW);
   const int iy = pix / IW, ix = pix - iy * IW;
   int oy0 = 0, oy1 = OH - 1, ox0 = 0, ox1 = OW - 1;
   if (sy > 0.f) { oy0 = max(0, (int)floorf((float)(iy - 1) / sy) - 1); oy1 = min(OH - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
@@ -475,16 +476,24 @@ __global__ __launch_bounds__(256) void bilinear_resize_adjoint_kernel(const void
     for (int q = 1; q < rows; ++q)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += red[(q * nv + cv) * VEC + i];
-    stv<T>(gin, (size_t)blockIdx.y * vpc + v0 + cv, EV<T>::pack(acc));
+    stv<T>(gin, bidx * vpc + v0 + cv, EV<T>::pack(acc));
   }
 }
 hipError_t launch_bilinear_resize_adjoint(int dtype, const void* gout, void* gin, int N, int IH, int IW, int OH, int OW, int C, hipStream_t st) {
   OCTSEG_NO_F16(dtype);
   const int vec = dtype == DT_F32 ? 4 : 8;
-  if (C % vec != 0 || (long long)N * IH * IW > 65535) return hipErrorInvalidValue;
+  if (C % vec != 0) return hipErrorInvalidValue;
   const int vpc = C / vec;
   const float sy = resize_scale(IH, OH), sx = resize_scale(IW, OW);
-  const dim3 grid((vpc + DW_CH - 1) / DW_CH, N * IH * IW);
+  const long long npx = (long long)N * IH * IW;
+  int gy = (int)npx, gz = 1;
+  if (npx > 65535) {                       // one workgroup per source pixel: factor the count into grid.y x grid.z exactly
+    gy = 0;
+    for (int d = 65535; d >= 1; --d) if (npx % d == 0) { gy = d; break; }
+    gz = (int)(npx / gy);
+    if (gz > 65535) return hipErrorInvalidValue;
+  }
+  const dim3 grid((vpc + DW_CH - 1) / DW_CH, gy, gz);
   if (dtype == DT_F32) hipLaunchKernelGGL(bilinear_resize_adjoint_kernel<float>, grid, dim3(256), 0, st, gout, gin, IH, IW, OH, OW, vpc, sy, sx);
   else hipLaunchKernelGGL(bilinear_resize_adjoint_kernel<bf16_t>, grid, dim3(256), 0, st, gout, gin, IH, IW, OH, OW, vpc, sy, sx);
   return hipGetLastError();

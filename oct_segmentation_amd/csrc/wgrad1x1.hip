@@ -40,6 +40,7 @@ struct Wgrad1x1Args {
   int Cin, Cout;
   float* dW;                              // [Cout][Cin] fp32 (tap slab already applied), accumulated with atomics
   int spw;                                // stages per workgroup (split-K)
+  int co_fast;                            // co tiles fastest in the XCD-local order (speed only)
 };
 
 // DEEP = 0: ring of 3 x 24 KB (MB = 2) / 4 x 16 KB (MB = 1), two workgroups per CU; DEEP = 1: 6 x 24 KB / 8 x 16 KB, one workgroup per CU
@@ -64,9 +65,19 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const Wgrad1x1Args a) {
   {
     const int gx_ = gridDim.x, gy_ = gridDim.y, gz_ = gridDim.z;
     const int total = gx_ * gy_ * gz_;
-    if ((total & 7) == 0 && (gz_ & 7) == 0) {
-      const int lid = bx + gx_ * (by + gy_ * bz);
-      const int w = (lid & 7) * (total >> 3) + (lid >> 3);
+    // Round 4: the placement is made of GROUPS -- the gy co-tile workgroups of one (ci tile, pixel slice) share the x tile -- dealt to the XCDs
+    // whole, consecutive groups of a pixel slice to the same XCD round (they share the dy tiles).  It needs gx * gz groups divisible by 8;
+    // round 3's form (whole pixel slices per XCD) needed gz % 8 == 0 and was therefore OFF on the big decoder layers, where split-K is 4:
+    // 1024->256 @176^2 fetched 3.05 GB for 1.27 GB of operands.  a.co_fast = 0 (OCTSEG_WGRAD_CI_MAJOR=1) restores round 3's rule for A/B.
+    const int groups = gx_ * gz_;
+    const int lid = bx + gx_ * (by + gy_ * bz);
+    if (a.co_fast && (groups & 7) == 0) {
+      const int x = lid & 7, q = lid >> 3;          // XCD, position inside the XCD's share
+      const int k = q / gy_, r = q - k * gy_;
+      const int g = x * (groups >> 3) + k;          // XCD x owns groups [x G / 8, (x + 1) G / 8): neighbouring ci tiles of a pixel slice share dy in ONE L2
+      by = r; bz = g / gx_; bx = g - bz * gx_;
+    } else if (!a.co_fast && (total & 7) == 0 && (gz_ & 7) == 0) {
+      const int w = (lid & 7) * (total >> 3) + (lid >> 3);   // XCD k owns the z range [k * gz / 8, (k + 1) * gz / 8)
       bz = w / (gx_ * gy_);
       const int rem = w - bz * (gx_ * gy_);
       by = rem / gx_; bx = rem - by * gx_;
@@ -306,6 +317,8 @@ hipError_t launch_wgrad1x1(int dtype, const WgradArgs& w, hipStream_t st) {
   const long long spw = (ns_total + ks - 1) / ks;
   ks = (ns_total + spw - 1) / spw;
   a.spw = (int)spw;
+  static const bool ci_major = getenv("OCTSEG_WGRAD_CI_MAJOR") != nullptr;   // A/B switch
+  a.co_fast = ci_major ? 0 : 1;
   if (deep) {
     if (MB == 2) return aff ? launch_w1<2, true, true>(a, gx, gy, (int)ks, st) : launch_w1<2, false, true>(a, gx, gy, (int)ks, st);
     return aff ? launch_w1<1, true, true>(a, gx, gy, (int)ks, st) : launch_w1<1, false, true>(a, gx, gy, (int)ks, st);

@@ -55,8 +55,18 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
   {
     const int gx_ = gridDim.x, gy_ = gridDim.y, gz_ = gridDim.z;
     const int total = gx_ * gy_ * gz_;
-    if ((total & 7) == 0 && (gz_ & 7) == 0) {
-      const int lid = bx + gx_ * (by + gy_ * bz);
+    // Round 4: the placement is made of GROUPS -- the gy co-tile workgroups of one (ci tile, pixel slice) share the x tile -- dealt to the XCDs
+    // whole, consecutive groups of a pixel slice to the same XCD round (they share the dy tiles).  It needs gx * gz groups divisible by 8;
+    // round 3's form (whole pixel slices per XCD) needed gz % 8 == 0 and was therefore OFF on the big decoder layers, where split-K is 4:
+    // 1024->256 @176^2 fetched 3.05 GB for 1.27 GB of operands.  a.co_fast = 0 (OCTSEG_WGRAD_CI_MAJOR=1) restores round 3's rule for A/B.
+    const int groups = gx_ * gz_;
+    const int lid = bx + gx_ * (by + gy_ * bz);
+    if (a.co_fast && (groups & 7) == 0) {
+      const int x = lid & 7, q = lid >> 3;          // XCD, position inside the XCD's share
+      const int k = q / gy_, r = q - k * gy_;
+      const int g = x * (groups >> 3) + k;          // XCD x owns groups [x G / 8, (x + 1) G / 8): neighbouring ci tiles of a pixel slice share dy in ONE L2
+      by = r; bz = g / gx_; bx = g - bz * gx_;
+    } else if (!a.co_fast && (total & 7) == 0 && (gz_ & 7) == 0) {
       const int w = (lid & 7) * (total >> 3) + (lid >> 3);   // XCD k owns the z range [k * gz / 8, (k + 1) * gz / 8)
       bz = w / (gx_ * gy_);
       const int rem = w - bz * (gx_ * gy_);
@@ -490,6 +500,8 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   if (ks < 1) ks = 1;
   if (deterministic_mode()) ks = 1;   // every dW element then has ONE writer (its atomicAdd meets a zeroed buffer): a fixed summation order
   a.ksplit = ks;
+  static const bool ci_major = getenv("OCTSEG_WGRAD_CI_MAJOR") != nullptr;   // A/B switch
+  a.co_fast = ci_major ? 0 : 1;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad_mfma_kernel<T, NTAPS>,

@@ -3,7 +3,9 @@
 # usage: bash tools/collect_profiles.sh <tag>
 set -e
 tag=${1:-r1}
+part=${2:-all}      # core | workloads | all (two gpurun calls when the whole list does not fit one call's time limit)
 cd /root/repo; export TMPDIR=/tmp
+if [ "$part" != "workloads" ]; then
 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_w -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${tag}_w.log 2>&1
 python3 tools/prof_summary.py $(ls gpurun_out/prof_${tag}_w/*/*.db | head -1) gpurun_out/${tag}_w_bench_kernel_stats.csv 8 > gpurun_out/prof_${tag}_w.txt
@@ -15,7 +17,10 @@ OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_alone.csv python3 bench.py --steps 
 python3 tools/group_layers.py gpurun_out/${tag}_layers_alone.csv 2 > gpurun_out/${tag}_layer_groups.txt
 python3 bench.py --workload ensemble_704_fp16 --steps 30 > gpurun_out/${tag}_ensemble_b1.json 2> /dev/null
 python3 bench.py --workload ensemble_704_fp16 --steps 20 --batch 8 > gpurun_out/${tag}_ensemble_b8.json 2> /dev/null
-for w in linknet_r50_704 unet_r50_704 fpn_r50_704 deeplabv3plus_r50_704 pspnet_r50_704 deeplabv3_r50_704; do
+fi
+if [ "$part" != "core" ]; then
+for w in linknet_r50_704 unet_r50_704 fpn_r50_704 deeplabv3plus_r50_704 pspnet_r50_704 deeplabv3_r50_704 manet_r50_704 pan_r50_704 unet_regnetx064_704 unet_regnety120_704 \
+         fpn_regnetx002_704 unet_effb0_704 fpn_effb5_704; do
   OCTSEG_PROFILE_DUMP=gpurun_out/${tag}_layers_$w.csv python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_$w.json 2> /dev/null
   python3 tools/group_layers.py gpurun_out/${tag}_layers_$w.csv 2 > gpurun_out/${tag}_layer_groups_$w.txt; rm -f gpurun_out/${tag}_layers_$w.csv
 done
@@ -23,3 +28,4 @@ for b in 2 4; do python3 bench.py --batch $b --steps 20 --warmup 5 --no-cpu-base
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/${tag}_bench_force_exchange.json 2> /dev/null
 python3 bench.py --batch 2 --steps 20 --warmup 5 --no-cpu-baseline --train-graph > gpurun_out/${tag}_bench_batch2_train_graph.json 2> /dev/null
 tail -c 600 gpurun_out/${tag}_bench_default.err
+fi

@@ -21,13 +21,14 @@ for k in res['FETCH_SIZE']:
     f_kib, n = res['FETCH_SIZE'][k]
     w_kib, _ = res['WRITE_SIZE'].get(k, (0.0, n))
     rows[k] = {'launches': n, 'fetch_bytes_per_launch': 2.0 * f_kib * 1024 / n, 'write_bytes_per_launch': w_kib * 1024 / n}
-FAMILY = ('conv_mfma_kernel', 'conv3x3p_kernel', 'wgrad_mfma_kernel', 'gemm1x1_kernel', 'thin_conv_kernel', 'thin_wgrad_kernel')
+FAMILY = ('conv_mfma_kernel', 'conv3x3p_kernel', 'wgrad_mfma_kernel', 'wgrad1x1_kernel', 'gemm1x1_kernel', 'thin_conv_kernel', 'thin_wgrad_kernel')
 conv = {k: v for k, v in rows.items() if any(f in k for f in FAMILY)}
 tot_l = sum(v['launches'] for v in conv.values())
 summary = {'kernels': rows,
            'mfma_family': {'launches': tot_l,
                            'hbm_bytes_per_launch': sum((v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) * v['launches'] for v in conv.values()) / max(1, tot_l)},
-           'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; 2 steps (1 warm-up + 1 timed) of bench.py, U-Net++/resnet101 704^2 bf16 B=16'}
+           'note': 'FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; 5 steps (1 warm-up + 1 timed + 3 of the kernels-alone pass) of bench.py, U-Net++/resnet101 704^2 bf16 B=16'}
+summary['mfma_family']['hbm_bytes_per_step'] = summary['mfma_family']['hbm_bytes_per_launch'] * tot_l / 5.0
 os.makedirs('profiles', exist_ok=True)
 json.dump(summary, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
 os.makedirs('gpurun_out', exist_ok=True)
