@@ -1936,7 +1936,12 @@ static void slice_plan(const octseg_plan* P, SliceCtx& S) {
     if (op.kind == OP_CONV) { touch(oi, P->convs[op.conv].w); touch(oi, P->convs[op.conv].b); }
     else if (op.kind == OP_BN_FIN) { if (P->bns[op.bn].lazy) { touch(oi, P->bns[op.bn].gamma); touch(oi, P->bns[op.bn].beta); } }
     else if (op.kind == OP_GN) { touch(oi, P->gns[op.gn].gamma); touch(oi, P->gns[op.gn].beta); }
-    else if (op.kind == OP_DW) touch(oi, op.dwp);
+    else if (op.kind == OP_DW || op.kind == OP_DWG) touch(oi, op.dwp);
+    else if (op.kind == OP_BNX) { touch(oi, P->bns[op.y.bn].gamma); touch(oi, P->bns[op.y.bn].beta); }
+    else if (op.kind == OP_SEFC) { for (int i = 0; i < 4; ++i) touch(oi, op.ins[i]); }
+    else if (op.kind == OP_FPA) {
+      for (int l = 0; l < 6; ++l) { touch(oi, P->fpa.w[l]); touch(oi, P->fpa.b[l]); touch(oi, P->bns[P->fpa.bn[l]].gamma); touch(oi, P->bns[P->fpa.bn[l]].beta); }
+    }
     else if (op.kind == OP_BN_ACT) {
       touch(oi, P->bns[op.y.bn].gamma); touch(oi, P->bns[op.y.bn].beta);
       if (op.res.t >= 0 && op.res.bn >= 0) { touch(oi, P->bns[op.res.bn].gamma); touch(oi, P->bns[op.res.bn].beta); }
