@@ -304,15 +304,28 @@ __device__ void pyr_resize(const float* in, float* out, int N, int IH, int IW, i
   }
   __syncthreads();
 }
-__device__ void pyr_resize_bwd(const float* dout, float* din, int N, int IH, int IW, int OH, int OW) {   // din += adjoint (float atomics inside ONE workgroup)
-  for (int e = threadIdx.x; e < N * OH * OW; e += PT) {
-    const int x = e % OW, y = (e / OW) % OH, n = e / (OW * OH);
-    int y0, y1, x0, x1; float ly, lx;
-    pyr_bil_coord(y, IH, OH, y0, y1, ly); pyr_bil_coord(x, IW, OW, x0, x1, lx);
-    float* p = din + n * IH * IW;
-    const float g = dout[e];
-    atomicAdd(p + y0 * IW + x0, (1.f - ly) * (1.f - lx) * g); atomicAdd(p + y0 * IW + x1, (1.f - ly) * lx * g);
-    atomicAdd(p + y1 * IW + x0, ly * (1.f - lx) * g); atomicAdd(p + y1 * IW + x1, ly * lx * g);
+__device__ void pyr_resize_bwd(const float* dout, float* din, int N, int IH, int IW, int OH, int OW) {   // din += adjoint, GATHER form: one owner per element,
+  // fixed summation order (no atomics: deterministic).  A source pixel is touched only by outputs whose two taps straddle it.
+  const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f, sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+  for (int e = threadIdx.x; e < N * IH * IW; e += PT) {
+    const int ix = e % IW, iy = (e / IW) % IH, n = e / (IW * IH);
+    int oy0 = 0, oy1 = OH - 1, ox0 = 0, ox1 = OW - 1;
+    if (sy > 0.f) { oy0 = max(0, (int)floorf((float)(iy - 1) / sy) - 1); oy1 = min(OH - 1, (int)ceilf((float)(iy + 1) / sy) + 1); }
+    if (sx > 0.f) { ox0 = max(0, (int)floorf((float)(ix - 1) / sx) - 1); ox1 = min(OW - 1, (int)ceilf((float)(ix + 1) / sx) + 1); }
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      int y0, y1; float ly;
+      pyr_bil_coord(oy, IH, OH, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        int x0, x1; float lx;
+        pyr_bil_coord(ox, IW, OW, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx != 0.f) acc = fmaf(wy * wx, dout[(n * OH + oy) * OW + ox], acc);
+      }
+    }
+    din[e] += acc;
   }
   __syncthreads();
 }

@@ -2550,7 +2550,7 @@ int octseg_net_train_step(octseg_plan* p, const float* params, float* grads, flo
     return run_backward(Eb, logits, target, grad_scale);
   };
   if (!p->tgraph_enabled || serial_mode()) return body();
-  octseg_plan::TrainKey key{params, grads, buffers, workspace, image, target, logits, loss, stats, stream, p->dropout_keep,
+  octseg_plan::TrainKey key{params, grads, buffers, workspace, image, target, logits, loss, stats, stream, p->dropout_keep, p->drop_connect,
                             normalize, {0, 0, 0}, {1, 1, 1}, grad_scale};
   if (normalize) for (int i = 0; i < 3; ++i) { key.mean[i] = mean[i]; key.stdv[i] = stdv[i]; }
   if (!(key == p->tgraph_key)) {

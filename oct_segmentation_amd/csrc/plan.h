@@ -203,11 +203,11 @@ struct octseg_plan {
   int tgraph_seen = 0;
   hipGraphExec_t tgraph_exec = nullptr;
   struct TrainKey {
-    const void *params, *grads, *buffers, *ws, *image, *target, *logits, *loss, *stats, *stream, *dropout;
+    const void *params, *grads, *buffers, *ws, *image, *target, *logits, *loss, *stats, *stream, *dropout, *drop_connect;
     int normalize; float mean[3], stdv[3], grad_scale;
     bool operator==(const TrainKey& o) const {
       return params == o.params && grads == o.grads && buffers == o.buffers && ws == o.ws && image == o.image && target == o.target &&
-             logits == o.logits && loss == o.loss && stats == o.stats && stream == o.stream && dropout == o.dropout &&
+             logits == o.logits && loss == o.loss && stats == o.stats && stream == o.stream && dropout == o.dropout && drop_connect == o.drop_connect &&
              normalize == o.normalize && grad_scale == o.grad_scale && mean[0] == o.mean[0] && mean[1] == o.mean[1] &&
              mean[2] == o.mean[2] && stdv[0] == o.stdv[0] && stdv[1] == o.stdv[1] && stdv[2] == o.stdv[2];
     }

@@ -477,6 +477,20 @@ class SegNet(nn.Module):
             raise ValueError(f'dropout_keep must be {list(shape)} of 0 / 1, got {tuple(keep.shape)}')
         return keep
 
+    def _drop_connect_factors(self, plan, B, device):
+        """EfficientNet: keep / (1 - rate) per id-skip block and sample -- floor(1 - rate + U[0, 1)) drawn here (efficientnet_pytorch's drop_connect),
+        or the injected `drop_connect_keep` pattern."""
+        lib = L.lib()
+        nb = lib.octseg_plan_num_drop_connect(plan.handle)
+        rates = torch.tensor([lib.octseg_plan_drop_connect_rate(plan.handle, i) for i in range(nb)], dtype=torch.float32, device=device)
+        keep = self.drop_connect_keep
+        if keep is None:
+            keep = torch.floor((1.0 - rates).view(-1, 1) + torch.rand(nb, B, device=device))
+        keep = keep.to(device, torch.float32)
+        if tuple(keep.shape) != (nb, B):
+            raise ValueError(f'drop_connect_keep must be [{nb}, {B}] of 0 / 1, got {tuple(keep.shape)}')
+        return (keep / (1.0 - rates).view(-1, 1)).contiguous()
+
     def _graph_train_step(self, image, target, normalize, mean, std, grad_scale):
         """forward + Dice + backward through octseg_net_train_step with the plan's training graph on: inputs are copied into persistent
         buffers (a replay needs every pointer unchanged), the step runs on a capturable stream, outputs come back as copies."""
@@ -508,6 +522,12 @@ class SegNet(nn.Module):
         io['mask'].copy_(target)
         if self._has_dropout():
             io['keep'].copy_(self._draw_keep(B, H, W, x.device))
+        if self.encoder_name.startswith('efficientnet-'):     # drop_connect factors in a persistent buffer (a replay needs every pointer unchanged)
+            fac = self._drop_connect_factors(plan, B, x.device)
+            if 'dc' not in io:
+                io['dc'] = torch.empty_like(fac)
+                L.check(L.lib().octseg_plan_set_drop_connect(plan.handle, L.ptr(io['dc'])))
+            io['dc'].copy_(fac)
         m = (C.c_float * 3)(*([float(v) for v in mean] if normalize else [0, 0, 0]))
         s = (C.c_float * 3)(*([float(v) for v in std] if normalize else [1, 1, 1]))
         cur = torch.cuda.current_stream(x.device)
@@ -541,17 +561,8 @@ class SegNet(nn.Module):
         if train:
             plan.stem_frame = x        # octseg.h: `image` must outlive the backward (the stem weight gradient reads it again)
         if train and self.encoder_name.startswith('efficientnet-'):
-            lib = L.lib()
-            nb = lib.octseg_plan_num_drop_connect(plan.handle)
-            rates = torch.tensor([lib.octseg_plan_drop_connect_rate(plan.handle, i) for i in range(nb)], dtype=torch.float32, device=x.device)
-            keep = self.drop_connect_keep
-            if keep is None:
-                keep = torch.floor((1.0 - rates).view(-1, 1) + torch.rand(nb, B, device=x.device))
-            keep = keep.to(x.device, torch.float32)
-            if tuple(keep.shape) != (nb, B):
-                raise ValueError(f'drop_connect_keep must be [{nb}, {B}] of 0 / 1, got {tuple(keep.shape)}')
-            plan.dc_factors = (keep / (1.0 - rates).view(-1, 1)).contiguous()     # kept alive with the plan: the backward reads it too
-            L.check(lib.octseg_plan_set_drop_connect(plan.handle, L.ptr(plan.dc_factors)))
+            plan.dc_factors = self._drop_connect_factors(plan, B, x.device)     # kept alive with the plan: the backward reads it too
+            L.check(L.lib().octseg_plan_set_drop_connect(plan.handle, L.ptr(plan.dc_factors)))
         if self._has_dropout() and train:
             keep = self._draw_keep(B, H, W, x.device)
             plan.drop_keep = keep      # the backward of this step reads it too: keep it alive with the plan
