@@ -107,6 +107,10 @@ int octseg_plan_param_info(const octseg_plan* plan, int index, octseg_param_info
 int octseg_plan_num_bn(const octseg_plan* plan);
 int octseg_plan_bn_info(const octseg_plan* plan, int index, octseg_bn_info* out);
 double octseg_plan_fwd_macs(const octseg_plan* plan);      /* conv multiply-accumulates of one forward */
+/* multiply-accumulates a TRAINING step executes per pass: out3 = {forward, data gradient, weight gradient}.  Equal to fwd_macs unless the
+ * plan runs the decoder's (nearest x2, concat, 3x3) layers as a 4x4 stride-2 transposed conv over the low-resolution map plus a 3x3 over the
+ * skip channels (OCTSEG_TIED): the same function of the same weights in 16 instead of 36 products per source pixel. */
+int octseg_plan_exec_macs(const octseg_plan* plan, double* out3);
 /* test hook: workspace byte offsets of the raw output (NHWC, plan dtype) of conv layer `conv_name`
  * (module path, e.g. "decoder.blocks.0.conv1.0") and of its gradient; dims = {N,H,W,C}. */
 int octseg_plan_find_tensor(const octseg_plan* plan, const char* conv_name, size_t* act_off,

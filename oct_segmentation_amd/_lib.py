@@ -62,6 +62,7 @@ SYMBOLS = {
     'octseg_plan_num_bn': (C.c_int, [_P]),
     'octseg_plan_bn_info': (C.c_int, [_P, C.c_int, C.POINTER(BNInfo)]),
     'octseg_plan_fwd_macs': (C.c_double, [_P]),
+    'octseg_plan_exec_macs': (C.c_int, [_P, C.POINTER(C.c_double)]),
     'octseg_plan_find_tensor': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     'octseg_profile_start': (C.c_int, []),
     'octseg_profile_stop': (C.c_int, [C.POINTER(C.c_double)]),

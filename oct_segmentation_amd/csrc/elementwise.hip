@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char
     const PackJob jb = tab[lo];
     const float* w = params + jb.src_off;
     const int VPR = jb.RB / 16, KC = jb.RB / (int)sizeof(T), swz_div = 256 / jb.RB;
-    const int rows = jb.transpose ? jb.I : jb.O, K = jb.transpose ? jb.O : jb.I;
+    const int rows = jb.transpose ? jb.I : jb.O, K = jb.transpose ? jb.O : jb.I, sI = jb.src_I ? jb.src_I : jb.I;
     size_t rem = (size_t)(g - prefix[lo]);
     const size_t v = rem;
     const int q = (int)(rem % VPR); rem /= VPR;
@@ -1148,7 +1148,16 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char
     for (int i = 0; i < VEC; ++i) {
       const int c = c0 + i;
       float val = 0.f;
-      if (co < rows && c < K) val = jb.transpose ? w[((size_t)tap * jb.O + c) * jb.I + co] : w[((size_t)tap * jb.O + co) * jb.I + c] * osc;
+      if (co < rows && c < K) {
+        const int o = jb.transpose ? c : co, ci = (jb.transpose ? co : c) + jb.src_c0;
+        if (!jb.tied) val = w[((size_t)tap * jb.O + o) * sI + ci];
+        else {   // 4x4 stride-2 kernel of (nearest x2, then the 3x3 source): the source taps that land on the same low-resolution pixel, summed in f32
+          const int u = tap >> 2, vv = tap & 3;
+          for (int r3 = max(0, 2 - u); r3 <= min(2, 3 - u); ++r3)
+            for (int s3 = max(0, 2 - vv); s3 <= min(2, 3 - vv); ++s3) val += w[((size_t)(r3 * 3 + s3) * jb.O + o) * sI + ci];
+        }
+        if (!jb.transpose) val *= osc;
+      }
       x[i] = val;
     }
     stv<T>(ws + jb.dst_off, v, EV<T>::pack(x));
@@ -1160,6 +1169,31 @@ hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJ
   if (dtype == DT_F16) hipLaunchKernelGGL(pack_all_kernel<f16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
   else if (dtype == DT_F32) hipLaunchKernelGGL(pack_all_kernel<float>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
   else hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(gr), dim3(256), 0, st, params, (char*)ws, tab, prefix, njobs, total, fold);
+  return hipGetLastError();
+}
+
+// gradient of a tied 4x4 image (and of the skip slice's own 3x3 image) folded back into the 3x3 weight gradient
+__global__ __launch_bounds__(256) void tied_fold_kernel(const float* dK4, const float* dW3s, float* dW3, int O, int Ca, int Cs) {
+  const int I = Ca + Cs;
+  const size_t total = (size_t)9 * O * I;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % I);
+    const int o = (int)((idx / I) % O);
+    const int t = (int)(idx / ((size_t)I * O));
+    float val;
+    if (i < Ca) {
+      const int r3 = t / 3, s3 = t - 3 * r3;   // tap r3 lies in A(2 - r3) and A(3 - r3)
+      val = 0.f;
+      for (int u = 2 - r3; u <= 3 - r3; ++u)
+        for (int v = 2 - s3; v <= 3 - s3; ++v) val += dK4[((size_t)(u * 4 + v) * O + o) * Ca + i];
+    } else {
+      val = dW3s[((size_t)t * O + o) * Cs + (i - Ca)];
+    }
+    dW3[idx] += val;
+  }
+}
+hipError_t launch_tied_fold(const float* dK4, const float* dW3s, float* dW3, int O, int Ca, int Cs, hipStream_t st) {
+  hipLaunchKernelGGL(tied_fold_kernel, dim3(grid_for((size_t)9 * O * (Ca + Cs), 256)), dim3(256), 0, st, dK4, dW3s, dW3, O, Ca, Cs);
   return hipGetLastError();
 }
 

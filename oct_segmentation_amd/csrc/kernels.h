@@ -229,7 +229,14 @@ hipError_t launch_pack_weight_image(int dtype, const float* w, void* img, int ta
 // every weight image of a plan in one launch (job table + prefix sums live in the workspace)
 struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, transpose, BN, RB, nchunks, ntiles;
                  size_t scale_off; /* bytes in the workspace: eval scale[O] of the BatchNorm behind this conv, folded into the
-                                      forward image when packing for eval (~0: none) */ };
+                                      forward image when packing for eval (~0: none) */
+                 int src_I;        /* row length of the SOURCE weight when the image covers a channel slice of it (0: I) */
+                 int src_c0;       /* first source channel of that slice */
+                 int tied;         /* 1: taps == 16, the image is the 4x4 stride-2 kernel that a nearest-x2 upsample followed by the 3x3
+                                         source is equal to: K4[u][v] = sum of W3[r][s] over r in A(u), s in A(v), A(k) = [max(0, 2 - k), min(2, 3 - k)] */ };
+// gradient of the tied image back into the 3x3 weight it was derived from: dW3[t][o][i] += (i < Ca ? sum of dK4 over the (u, v) whose
+// A(u) x A(v) holds tap t : dW3s[t][o][i - Ca]);  dK4 [16][O][Ca], dW3s [9][O][Cs] (nullptr when Cs == 0), dW3 [9][O][Ca + Cs], all f32
+hipError_t launch_tied_fold(const float* dK4, const float* dW3s, float* dW3, int O, int Ca, int Cs, hipStream_t st);
 hipError_t launch_pack_all(int dtype, const float* params, void* ws, const PackJob* tab, const unsigned long long* prefix, int njobs,
                            unsigned long long total, int fold, hipStream_t st);
 

@@ -193,6 +193,40 @@ static void wgrad_launches(const Geom& g, std::vector<WgradArgs>& out) {
   }
 }
 
+// Data gradient of the tied ConvTranspose2d (Geom of the ConvT: IH x IW = the low-resolution map): the adjoint of each forward parity launch is a
+// stride-1 2x2-tap conv over ONE parity plane of dy (the caller presents the plane as a tensor of its own: pointer offset, doubled pixel and row
+// strides), all four accumulating into the low-resolution gradient.  Four launches of 4 taps over 176^2 planes instead of one 16-tap stride-2
+// launch whose 34 x 34 window does not fit a double-buffered LDS tile.  out[k] belongs to parity (k >> 1, k & 1).
+static void tied_dgrad_launches(const Geom& g, std::vector<ConvArgs>& out) {
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      int n = 0;
+      for (int r = 0; r < g.R; ++r) {
+        if (((py + g.pad - r) & 1) != 0) continue;
+        for (int s = 0; s < g.S; ++s) {
+          if (((px + g.pad - s) & 1) != 0) continue;
+          a.tap_dy[n] = -((py + g.pad - r) / 2); a.tap_dx[n] = -((px + g.pad - s) / 2); a.tap_w[n] = r * g.S + s; ++n;
+        }
+      }
+      set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+      a.istride = 1; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.IH; a.OW = g.IW;
+      a.Cin = g.Cout; a.Cout = g.Cin; a.ostride = 1;
+      out.push_back(a);
+    }
+}
+
+static double layer_macs(const ConvLayer& L);
+
+// OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie)
+static int tie_mask() {   // (read when a plan is built, so that one process can hold plans of both kinds)
+  const char* e = getenv("OCTSEG_TIED");
+  int v = 0;
+  if (e != nullptr) for (const char* c = e; *c; ++c) v |= *c == 'f' ? 1 : *c == 'd' ? 2 : *c == 'w' ? 4 : 0;
+  return v;
+}
+
 // ================================================================ graph builder
 // The side stream carries work that is off the critical chain (weight gradients, the second forward lane).  OCTSEG_SIDE_PRIORITY=low
 // creates it with the lowest stream priority, so that the chain's kernels win the dispatch whenever compute units free up (A/B switch).
@@ -1142,7 +1176,7 @@ static int build_plan(octseg_plan* P) {
     P->dz4_off = off; off += align_up((size_t)P->B * h4 * w4 * 16 * esz);
   }
   for (auto& bn : P->bns) { bn.ss_off = off; off += align_up((size_t)bn.C * 6 * sizeof(float)); }
-  size_t slab = 0, tmp = 0;
+  size_t slab = 0, tmp = 0, tie_scratch = 0;
   for (auto& L : P->convs) {
     Geom g{L.R, L.S, L.stride, L.pad, L.transposed, L.N, L.IH, L.IW, L.Cin, L.OH, L.OW, L.Cout};
     if (L.stem) { g.R = g.S = 1; g.pad = 0; }
@@ -1162,7 +1196,39 @@ static int build_plan(octseg_plan* P) {
       L.pk_dgrad = conv_pack_info(d0, P->dtype);
       L.wimg_dgrad_off = off; off += align_up(conv_image_bytes(L.pk_dgrad, wtaps));
     }
-    if (L.bn >= 0 && L.stem && (P->stem_k == 7 && thin_stem_eligible(P->dtype))) {
+    L.tie = 0;
+    if (tie_mask() != 0 && esz == 2 && !L.transposed && !L.stem && !L.head && !L.sliced && !L.accum_out && L.R == 3 && L.S == 3 && L.stride == 1 &&
+        L.pad == 1 && L.bn >= 0 && L.b < 0 && !L.srcs.empty() && L.srcs[0].up && L.srcs[0].cn == 0 && P->tensors[L.srcs[0].v.t].need_grad) {
+      bool ok = true;
+      for (size_t i = 1; i < L.srcs.size(); ++i) ok = ok && !L.srcs[i].up && L.srcs[i].cn == 0 && P->tensors[L.srcs[i].v.t].need_grad;
+      const int Ca = P->tensors[L.srcs[0].v.t].C, Cs = L.Cin - Ca;
+      // (narrow layers stay whole: below 64 channels a launch is a single K chunk and the thin kernels own the 16 / 32-channel decoder tail)
+      if (ok && Ca >= 64 && Ca % 8 == 0 && Cs % 8 == 0 && L.Cout >= 32 && (Cs == 0 || Cs >= 32)) {
+        L.tie = tie_mask(); L.tie_Ca = Ca; L.tie_Cs = Cs;
+        const Geom gu{4, 4, 2, 1, true, L.N, L.IH / 2, L.IW / 2, Ca, L.OH, L.OW, L.Cout};
+        const Geom gs{3, 3, 1, 1, false, L.N, L.IH, L.IW, Cs, L.OH, L.OW, L.Cout};
+        std::vector<ConvArgs> v;
+        fwd_launches(gu, v);
+        L.tie_pk_fu = conv_pack_info(v[0], P->dtype);
+        L.tie_fu_off = off; off += align_up(conv_image_bytes(L.tie_pk_fu, 16));
+        v.clear(); tied_dgrad_launches(gu, v);
+        L.tie_pk_du = conv_pack_info(v[0], P->dtype);
+        L.tie_du_off = off; off += align_up(conv_image_bytes(L.tie_pk_du, 16));
+        if (Cs > 0) {
+          v.clear(); fwd_launches(gs, v);
+          L.tie_pk_fs = conv_pack_info(v[0], P->dtype);
+          L.tie_fs_off = off; off += align_up(conv_image_bytes(L.tie_pk_fs, 9));
+          v.clear(); dgrad_launches(gs, v);
+          L.tie_pk_ds = conv_pack_info(v[0], P->dtype);
+          L.tie_ds_off = off; off += align_up(conv_image_bytes(L.tie_pk_ds, 9));
+        }
+        tie_scratch = std::max(tie_scratch, ((size_t)16 * Ca + (size_t)9 * Cs) * L.Cout * sizeof(float));
+      }
+    }
+    if ((L.tie & 1) && L.bn >= 0) {
+      P->bns[L.bn].rows = 512;   // the launches accumulate into the output: its statistics come from a sweep over the finished tensor
+      slab = std::max(slab, (size_t)512 * L.Cout * 2 * sizeof(float));
+    } else if (L.bn >= 0 && L.stem && (P->stem_k == 7 && thin_stem_eligible(P->dtype))) {
       P->bns[L.bn].rows = thin_stem_rows(L.N, P->H, P->W);   // the stem runs in thin.hip straight from the frame: one slab row per workgroup
       slab = std::max(slab, (size_t)P->bns[L.bn].rows * L.Cout * 2 * sizeof(float));
     } else if (L.bn >= 0) {
@@ -1205,6 +1271,20 @@ static int build_plan(octseg_plan* P) {
       P->pack_jobs.push_back(j);
       P->pack_total += (unsigned long long)taps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
     }
+    if (L.tie) {   // the tied images: 4x4 kernel over the upsampled source's channels, the plain 3x3 over the skip channels (training only: no fold)
+      auto add = [&](size_t dst, int ntaps, int I, int c0, int tr, int tied, const ConvPackInfo& pk) {
+        PackJob j{P->params[L.w].off, dst, ntaps, L.Cout, I, tr, pk.BN, pk.RB, pk.nchunks, pk.ntiles, ~(size_t)0, L.Cin, c0, tied};
+        P->pack_prefix.push_back(P->pack_total);
+        P->pack_jobs.push_back(j);
+        P->pack_total += (unsigned long long)ntaps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
+      };
+      add(L.tie_fu_off, 16, L.tie_Ca, 0, 0, 1, L.tie_pk_fu);
+      add(L.tie_du_off, 16, L.tie_Ca, 0, 1, 1, L.tie_pk_du);
+      if (L.tie_Cs > 0) {
+        add(L.tie_fs_off, 9, L.tie_Cs, L.tie_Ca, 0, 0, L.tie_pk_fs);
+        add(L.tie_ds_off, 9, L.tie_Cs, L.tie_Ca, 1, 0, L.tie_pk_ds);
+      }
+    }
   }
   P->bn_jobs.clear(); P->bn_prefix.clear(); P->bn_total = 0;
   for (auto& b : P->bns) {
@@ -1232,6 +1312,12 @@ static int build_plan(octseg_plan* P) {
     P->pool_idx_off = off; off += align_up(pool_elems);   // one buffer: the ResNet stems have exactly one max-pool
   }
   P->tmp_off = off; P->tmp_bytes = tmp; off += align_up(tmp);
+  P->tie_scratch_off = off; off += align_up(tie_scratch);
+  for (int k = 0; k < 3; ++k) {
+    P->exec_macs[k] = P->fwd_macs;
+    for (auto& L : P->convs)   // a tied pass runs 16 of the 36 multiply-accumulates per low-resolution pixel over the upsampled source's channels
+      if (L.tie & (1 << k)) P->exec_macs[k] -= layer_macs(L) * L.tie_Ca / L.Cin * (5.0 / 9.0);
+  }
   {
     size_t se_part = 0;
     for (auto& op : P->ops)
@@ -1350,6 +1436,44 @@ static int pack_all_weights(Exec& E, bool fold) {
 
 static const void* fwd_weight(const Exec& E, const ConvLayer& L) { return E.ws + L.wimg_fwd_off; }
 
+static Geom tie_geom_up(const ConvLayer& L) { return Geom{4, 4, 2, 1, true, L.N, L.IH / 2, L.IW / 2, L.tie_Ca, L.OH, L.OW, L.Cout}; }
+static Geom tie_geom_skip(const ConvLayer& L) { return Geom{3, 3, 1, 1, false, L.N, L.IH, L.IW, L.tie_Cs, L.OH, L.OW, L.Cout}; }
+
+// Training forward of a tied layer (ConvLayer::tie & 1): the skip channels' 3x3 stores the output, the four parity launches of the 4x4
+// stride-2 kernel over the low-resolution source add to it, one sweep takes the BatchNorm statistics of the finished tensor.
+static int tied_forward(Exec& E, const ConvLayer& L, hipStream_t st, float* slab) {
+  octseg_plan* P = E.P;
+  SrcDesc src[MAX_SRC];
+  const int ns = E.fill_srcs(L, src);
+  DstDesc d;
+  d.ptr = E.act(L.out); d.C = L.Cout; d.c0 = 0; d.cn = L.Cout; d.H = L.OH; d.W = L.OW; d.accum = 0; d.pool = 0;
+  const double macs = layer_macs(L);   // (profile classes keep the reference graph's count: the nine taps over every upsampled pixel)
+  if (L.tie_Cs > 0) {
+    std::vector<ConvArgs> v;
+    fwd_launches(tie_geom_skip(L), v);
+    ConvArgs& a = v[0];
+    a.nsrc = ns - 1;
+    for (int i = 1; i < ns; ++i) { a.src[i - 1] = src[i]; a.src[i - 1].c0 -= L.tie_Ca; }
+    a.W = E.ws + L.tie_fs_off;
+    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE;
+    ProfScope ps(0, 2.0 * macs * L.tie_Cs / L.Cin, st, L.name);
+    HIPCHK(launch_conv(P->dtype, a, st));
+  }
+  std::vector<ConvArgs> v;
+  fwd_launches(tie_geom_up(L), v);
+  for (auto& a : v) {
+    a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
+    a.W = E.ws + L.tie_fu_off;
+    d.accum = L.tie_Cs > 0 ? 1 : 0;   // (the four parities are disjoint: without a skip launch each one stores its own pixels)
+    a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE;
+    ProfScope ps(0, 2.0 * macs * L.tie_Ca / L.Cin / 4.0, st, L.name);
+    HIPCHK(launch_conv(P->dtype, a, st));
+  }
+  const BNInfo& b = P->bns[L.bn];
+  HIPCHK(launch_tensor_stats(P->dtype, E.act(L.out), (size_t)L.N * L.OH * L.OW, b.C, slab, b.rows, st));
+  return OCTSEG_OK;
+}
+
 static int run_forward(Exec& E, const float* image, float* logits, int normalize, const float* mean, const float* stdv) {
   octseg_plan* P = E.P;
   if (!P->run_error.empty()) return fail(OCTSEG_BAD_SHAPE, P->run_error);
@@ -1437,6 +1561,12 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
             P->stem_image = image; P->stem_normalize = normalize;
             for (int i = 0; i < 3; ++i) { P->stem_mean[i] = sa.mean[i]; P->stem_std[i] = sa.stdv[i]; }
           }
+          tseq[L.out] = stamp;
+          break;
+        }
+        if ((L.tie & 1) && E.train && !folded) {
+          rc = tied_forward(E, L, st, slab_l);
+          if (rc) return rc;
           tseq[L.out] = stamp;
           break;
         }
@@ -1819,7 +1949,36 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   // bias gradient
   if (L.b >= 0)
     HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, ws_));
-  {
+  if (L.tie & 4) {
+    // tied: gradient of the 4x4 image (low-resolution source x dy's parity planes) and of the skip slice's 3x3 into scratch, folded into the
+    // 3x3 gradient by one sweep (the side stream runs the layers one after the other: one scratch serves them all)
+    SrcDesc src[MAX_SRC];
+    const int ns = E.fill_srcs(L, src);
+    const int Ca = L.tie_Ca, Cs = L.tie_Cs;
+    float* dK4 = (float*)(E.ws + P->tie_scratch_off);
+    float* dW3s = dK4 + (size_t)16 * L.Cout * Ca;
+    HIPCHK(hipMemsetAsync(dK4, 0, ((size_t)16 * Ca + (size_t)9 * Cs) * L.Cout * sizeof(float), ws_));
+    const double macs = layer_macs(L);
+    std::vector<WgradArgs> lw;
+    wgrad_launches(tie_geom_up(L), lw);
+    for (auto& a : lw) {
+      a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
+      a.dy = dy; a.dyC = dyC; a.dW = dK4; a.stamp = nullptr;
+      ProfScope ps(2, 2.0 * macs * Ca / L.Cin / 4.0, ws_, L.name);
+      HIPCHK(launch_wgrad(P->dtype, a, ws_));
+    }
+    if (Cs > 0) {
+      lw.clear();
+      wgrad_launches(tie_geom_skip(L), lw);
+      WgradArgs& a = lw[0];
+      a.nsrc = ns - 1;
+      for (int i = 1; i < ns; ++i) { a.src[i - 1] = src[i]; a.src[i - 1].c0 -= Ca; }
+      a.dy = dy; a.dyC = dyC; a.dW = dW3s; a.stamp = nullptr;
+      ProfScope ps(2, 2.0 * macs * Cs / L.Cin, ws_, L.name);
+      HIPCHK(launch_wgrad(P->dtype, a, ws_));
+    }
+    HIPCHK(launch_tied_fold(dK4, Cs > 0 ? dW3s : nullptr, E.grads + P->params[L.w].off, L.Cout, Ca, Cs, ws_));
+  } else {
     std::vector<WgradArgs> lw;
     wgrad_launches(g, lw);
     for (auto& a : lw) {
@@ -1835,6 +1994,54 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
   bool any = false;
   for (auto& s : L.srcs) any = any || P->tensors[s.v.t].need_grad;
   if (!any) return OCTSEG_OK;
+  if (L.tie & 2) {
+    // tied: the low-resolution source's gradient from the four parity planes of dy (2x2 taps each, all of them cover the whole map: the first
+    // stores unless somebody wrote before, the others add); the skip sources' from a 3x3 data gradient over their own channels
+    const int ti0 = L.srcs[0].v.t;
+    const TensorInfo& t0 = P->tensors[ti0];
+    const double macs = layer_macs(L);
+    std::vector<ConvArgs> lu;
+    tied_dgrad_launches(tie_geom_up(L), lu);
+    const int acc0 = E.claim(ti0);
+    for (int k = 0; k < 4; ++k) {
+      ConvArgs& a = lu[k];
+      const int py = k >> 1, px = k & 1;
+      SrcDesc s;
+      s.ptr = (const char*)dy + ((size_t)py * L.OW + px) * dyC * esz;
+      s.scale = nullptr; s.shift = nullptr; s.C = 2 * dyC; s.c0 = 0; s.H = L.OH / 2; s.W = L.OW; s.up = 0; s.relu = 0;
+      a.src[0] = s; a.nsrc = 1;
+      a.Cin = L.Cout;
+      a.W = E.ws + L.tie_du_off;
+      DstDesc d;
+      d.ptr = E.grad(ti0); d.C = t0.C; d.c0 = 0; d.cn = L.tie_Ca; d.H = t0.H; d.W = t0.W; d.accum = k == 0 ? acc0 : 1; d.pool = 0;
+      a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
+      ProfScope ps(1, 2.0 * macs * L.tie_Ca / L.Cin / 4.0, E.st, L.name);
+      HIPCHK(launch_conv(P->dtype, a, E.st));
+    }
+    if (L.tie_Cs > 0) {
+      std::vector<ConvArgs> ls;
+      dgrad_launches(tie_geom_skip(L), ls);
+      ConvArgs& a = ls[0];
+      SrcDesc s;
+      s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
+      a.src[0] = s; a.nsrc = 1;
+      a.Cin = L.Cout;
+      a.W = E.ws + L.tie_ds_off;
+      int nd = 0, c0 = 0;
+      for (size_t i = 1; i < L.srcs.size(); ++i) {
+        const int ti = L.srcs[i].v.t;
+        const TensorInfo& t = P->tensors[ti];
+        DstDesc d;
+        d.ptr = E.grad(ti); d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = E.claim(ti); d.pool = 0;
+        a.dst[nd++] = d;
+        c0 += t.C;
+      }
+      a.ndst = nd; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
+      ProfScope ps(1, 2.0 * macs * L.tie_Cs / L.Cin, E.st, L.name);
+      HIPCHK(launch_conv(P->dtype, a, E.st));
+    }
+    return OCTSEG_OK;
+  }
   std::vector<ConvArgs> ld;
   dgrad_launches(g, ld);
   // destinations: the forward sources' gradient buffers; upsampled sources go through a temp.  A destination
@@ -2360,6 +2567,11 @@ size_t octseg_plan_buffer_numel(const octseg_plan* p) { return p ? p->buffer_num
 int octseg_plan_num_params(const octseg_plan* p) { return p ? (int)p->params.size() : 0; }
 int octseg_plan_num_bn(const octseg_plan* p) { return p ? (int)p->bns.size() : 0; }
 double octseg_plan_fwd_macs(const octseg_plan* p) { return p ? p->fwd_macs : 0.0; }
+int octseg_plan_exec_macs(const octseg_plan* p, double* out3) {
+  if (p == nullptr || out3 == nullptr) return OCTSEG_BAD_ARG;
+  for (int k = 0; k < 3; ++k) out3[k] = p->exec_macs[k];
+  return OCTSEG_OK;
+}
 
 int octseg_plan_param_info(const octseg_plan* p, int i, octseg_param_info* o) {
   if (!p || !o || i < 0 || i >= (int)p->params.size()) return fail(OCTSEG_BAD_ARG, "param index out of range");

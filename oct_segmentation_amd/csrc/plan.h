@@ -73,6 +73,13 @@ struct ConvLayer {
   int stem_k = 7;           // stem layers: kernel size of the im2col rows (7: torchvision ResNet, 3: timm RegNet)
   int fold_bn = -1;         // sliced layers: the BatchNorm of the whole tensor (not fed by this layer's epilogue in training); eval forwards
                             // fold its scale / shift for channels [out_c0, out_c0 + Cout) into this group's image and epilogue
+  // Tied decomposition (training, 2-byte dtypes): srcs[0] is read through a nearest-x2 upsample, so over its Ca channels the 3x3 is equal to a
+  // ConvTranspose2d(k4, s2, p1) of the LOW-resolution map with the 4x4 kernel K4 = sums of the 3x3 taps that land on one source pixel
+  // (kernels.h PackJob::tied) -- 16 instead of 36 multiply-accumulates per source pixel, channel pair.  The skip sources (Cs channels)
+  // keep their 3x3 as a launch of their own.  `tie` = which passes run that way: 1 forward, 2 data gradient, 4 weight gradient.
+  int tie = 0, tie_Ca = 0, tie_Cs = 0;
+  size_t tie_fu_off = 0, tie_fs_off = 0, tie_du_off = 0, tie_ds_off = 0;   // images: forward up / skip, data gradient up / skip
+  ConvPackInfo tie_pk_fu, tie_pk_fs, tie_pk_du, tie_pk_ds;
 };
 
 enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
@@ -164,6 +171,9 @@ struct octseg_plan {
   int stem_k = 7;                            // kernel size of the stem conv (7x7 s2 p3 ResNet, 3x3 s2 p1 RegNet): rows of OP_STEM_COL
   int dlogits_C = 16;
   double fwd_macs = 0;
+  double exec_macs[3] = {0, 0, 0};           // multiply-accumulates a training step EXECUTES per pass (forward, data gradient, weight gradient):
+                                             // below fwd_macs where the tied decomposition runs (ConvLayer::tie)
+  size_t tie_scratch_off = 0;                // f32 [16][O][Ca] + [9][O][Cs]: gradients of the tied images of ONE layer (folded into the 3x3 gradient)
   // side stream of the backward: weight gradients only depend on dy and on saved activations, so they run
   // beside the dgrad / BN-backward chain (MFMA-bound next to HBM-bound work)
   // weight images currently in the workspace correspond to (packed_params, packed_ws) unless invalidated

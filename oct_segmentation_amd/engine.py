@@ -447,6 +447,13 @@ class SegNet(nn.Module):
     def fwd_macs(self, B, H, W):
         return L.lib().octseg_plan_fwd_macs(self._plan(B, H, W).handle)
 
+    def exec_macs(self, B, H, W):
+        """(forward, data gradient, weight gradient) multiply-accumulates a training step executes (octseg_plan_exec_macs)."""
+        import ctypes
+        out = (ctypes.c_double * 3)()
+        L.check(L.lib().octseg_plan_exec_macs(self._plan(B, H, W).handle, out))
+        return tuple(out)
+
     def _check_input(self, x):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
             raise ValueError(f'expected a float32 CUDA tensor [B,3,H,W], got {tuple(x.shape)} {x.dtype} {x.device}')

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of the tied decomposition on the default workload: per pass and all together (one JSON line each)
+out=gpurun_out/tied_ab.txt; : > $out
+for t in "" d w dw fdw; do
+  echo "== OCTSEG_TIED=$t" >> $out
+  OCTSEG_TIED=$t python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        o = json.loads(l); r = o['roofline']
+        print(o['value'], 'frames/s', o['ms_per_step'], 'ms/step  mfma', r['kernel_ms_per_step'], 'ms', r['achieved'], 'TF/s', {k: v['ms_per_step'] for k, v in r['by_class'].items()}, r.get('executed'))
+" >> $out || exit 1
+done
+cat $out
