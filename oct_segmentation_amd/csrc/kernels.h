@@ -124,6 +124,10 @@ hipError_t launch_se_dgate(int dtype, const void* g, const void* x, const void* 
 // wgrad_mfma.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 // wgrad1x1.hip: stride-1 1x1 weight gradients (bf16, 64-divisible channel counts, flattened pixel list) as an LDS-DMA ring pipeline;
+// wgrad_convt.hip: ConvTranspose2d(k4, s2, p1) weight gradient, all four output parities (16 taps) in one launch; `a` = any of the four
+// per-parity launches of the transposed form (they share sources, extents, dy and dW)
+bool wgrad_convt16_eligible(const WgradArgs& a, int dtype);
+hipError_t launch_wgrad_convt16(int dtype, const WgradArgs& a, hipStream_t st);
 // launch_wgrad routes eligible launches there after flatten_1x1
 bool wgrad1x1_eligible(const WgradArgs& flattened, int dtype);
 hipError_t launch_wgrad1x1(int dtype, const WgradArgs& flattened, hipStream_t st);

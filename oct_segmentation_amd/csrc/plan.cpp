@@ -219,11 +219,15 @@ static void tied_dgrad_launches(const Geom& g, std::vector<ConvArgs>& out) {
 
 static double layer_macs(const ConvLayer& L);
 
-// OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie)
+// OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie).  Default `w`:
+// the weight gradient is the same fp32 sum of the same bf16 products in another order, 16 instead of 36 of them per source pixel (U-Net++/
+// resnet101 16 x 704^2: weight-gradient class 21.7 -> 20.3 ms, profiles/r4_tied_ab.txt).  `f` and `d` are exact up to bf16 rounding and, on the
+// generic 4-tap loop, not faster yet -- opt-in.  OCTSEG_TIED=0 (or any string without f / d / w): none.
 static int tie_mask() {   // (read when a plan is built, so that one process can hold plans of both kinds)
   const char* e = getenv("OCTSEG_TIED");
+  if (e == nullptr) return 4;
   int v = 0;
-  if (e != nullptr) for (const char* c = e; *c; ++c) v |= *c == 'f' ? 1 : *c == 'd' ? 2 : *c == 'w' ? 4 : 0;
+  for (const char* c = e; *c; ++c) v |= *c == 'f' ? 1 : *c == 'd' ? 2 : *c == 'w' ? 4 : 0;
   return v;
 }
 
@@ -1964,8 +1968,15 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     for (auto& a : lw) {
       a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
       a.dy = dy; a.dyC = dyC; a.dW = dK4; a.stamp = nullptr;
-      ProfScope ps(2, 2.0 * macs * Ca / L.Cin / 4.0, ws_, L.name);
-      HIPCHK(launch_wgrad(P->dtype, a, ws_));
+    }
+    if (wgrad_convt16_eligible(lw[0], P->dtype)) {   // all four parities from one staged window (wgrad_convt.hip)
+      ProfScope ps(2, 2.0 * macs * Ca / L.Cin, ws_, L.name);
+      HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
+    } else {
+      for (auto& a : lw) {
+        ProfScope ps(2, 2.0 * macs * Ca / L.Cin / 4.0, ws_, L.name);
+        HIPCHK(launch_wgrad(P->dtype, a, ws_));
+      }
     }
     if (Cs > 0) {
       lw.clear();
@@ -1986,7 +1997,15 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       a.dy = dy; a.dyC = dyC;
       a.dW = E.grads + P->params[L.w].off;
       a.stamp = nullptr;
-      ProfScope ps(2, 2.0 * layer_macs(L) / (double)lw.size(), ws_, L.name);
+    }
+    if (L.transposed && lw.size() == 4 && wgrad_convt16_eligible(lw[0], P->dtype)) {   // ConvTranspose2d: the four parities in one launch
+      ProfScope ps(2, 2.0 * layer_macs(L), ws_, L.name);
+      HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
+      lw.clear();
+    }
+    const double nl = (double)lw.size();
+    for (auto& a : lw) {
+      ProfScope ps(2, 2.0 * layer_macs(L) / nl, ws_, L.name);
       HIPCHK(launch_wgrad(P->dtype, a, ws_));
     }
   }
@@ -2937,8 +2956,12 @@ int octseg_conv2d_backward_weight(int dtype, const void* x, const void* dy, floa
   for (auto& a : lw) {
     SrcDesc s; s.ptr = x; s.scale = nullptr; s.shift = nullptr; s.C = Cin; s.c0 = 0; s.H = H; s.W = W; s.up = 0; s.relu = 0;
     a.src[0] = s; a.nsrc = 1; a.dy = dy; a.dyC = Cout; a.dW = dw; a.stamp = g_stamp;
-    HIPCHK(launch_wgrad(dtype, a, st));
   }
+  if (transposed && lw.size() == 4 && wgrad_convt16_eligible(lw[0], dtype)) {   // the plan's route for a ConvTranspose2d (conv_backward)
+    HIPCHK(launch_wgrad_convt16(dtype, lw[0], st));
+    return OCTSEG_OK;
+  }
+  for (auto& a : lw) HIPCHK(launch_wgrad(dtype, a, st));
   return OCTSEG_OK;
 }
 

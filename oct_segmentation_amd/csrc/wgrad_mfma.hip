@@ -33,6 +33,17 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 // MAXW = window passes held in registers by the prefetch pipeline (per tap count)
 template <int NTAPS> struct WgradCfg { static constexpr int MAXW = NTAPS == 1 ? 4 : (NTAPS == 4 ? 6 : 7); };
 
+// window-row-major contraction (pipelined == 2): MFMA slots of a tile before window row wr -- row w carries KS MFMAs for every output row
+// kk in [w - KS + 1, w] that exists
+__host__ __device__ constexpr int wrow_slots_before(int wr, int ks, int th) {
+  int n = 0;
+  for (int w = 0; w < wr; ++w) {
+    const int klo = w - (ks - 1) < 0 ? 0 : w - (ks - 1), khi = w < th ? w : th - 1;
+    n += (khi - klo + 1) * ks;
+  }
+  return n;
+}
+
 template <typename T, int NTAPS>
 __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, const int th, const int pipelined) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,13 +268,15 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
       for (int u = 0; u < MAXW; ++u) sg.write(ldsX, min(u, npw - 1), xv[u], xok[u]);
     };
     int tile = bz;
-    if constexpr (sizeof(T) == 2 && NTAPS == 9) {
+    if constexpr (sizeof(T) == 2 && (NTAPS == 9 || NTAPS == 4)) {
       if (pipelined == 2 && tile < ntiles) {
         // Two LDS tile buffers, ONE barrier per tile, and nothing but MFMAs on the critical path: while the 8 pixel rows
         // of tile k are contracted out of buffer k&1, the register-held loads of tile k+1 are stored into the other
         // buffer (rows 0-3) and the global loads of tile k+2 are issued into the same registers (rows 4-7), all as
         // fillers in the MFMA gaps (the wave is alone on its SIMD: a separate issue / store phase idles the pipe).
-        constexpr int TH8 = 8, NSLOT = TH8 * NTAPS, NITEM = MAXY + MAXW;
+        // KS = kernel extent (3x3, or the 2x2 taps of one ConvTranspose2d parity -- host-checked tap order, launch_wgrad_t): window rows of
+        // 16 + KS - 1 pixels, TH8 + KS - 1 of them
+        constexpr int TH8 = 8, NSLOT = TH8 * NTAPS, NITEM = MAXY + MAXW, KS = NTAPS == 9 ? 3 : 2, RWC = TW + KS - 1, NWR = TH8 + KS - 1;
         const int tile_bytes = (npy + npw) * PSTEP * PITCH;
         TilePos tp2{0, 0, 0};
         const char* yb2 = nullptr;
@@ -298,10 +311,10 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
         // the cycles in the MFMA pipe).  Window row w carries 3 / 6 / 9 MFMAs (rows 0 and 9 / 1 and 8 / 2..7): 72 per tile as before,
         // the same slot numbering for the staging fillers, fragments of window row w + 1 requested in the gaps of row w.
         struct Frag { s16x4_t lo, hi; };
-        Frag xs[2][3], ys[4];
+        Frag xs[2][KS], ys[4];
         auto rd_x = [&](const char* xbase, auto wc, auto sc, auto hc) __attribute__((always_inline)) {
           constexpr int Wn = decltype(wc)::value, S_ = decltype(sc)::value, H_ = decltype(hc)::value;
-          constexpr int OFF = (Wn * 18 + S_) * PITCH + H_ * 4 * PITCH;
+          constexpr int OFF = (Wn * RWC + S_) * PITCH + H_ * 4 * PITCH;
           if constexpr (H_ == 0) xs[Wn & 1][S_].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
           else xs[Wn & 1][S_].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xbase + OFF));
         };
@@ -311,24 +324,25 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
           if constexpr (H_ == 0) ys[Kn & 3].lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ybase + OFF));
           else ys[Kn & 3].hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ybase + OFF));
         };
-        // read q of the prefetch list of window row Wn: x (shift 0, 1, 2) x (lo, hi), then dy (lo, hi)
+        // read q of the prefetch list of window row Wn: x (shift 0 .. KS - 1) x (lo, hi), then dy (lo, hi)
         auto prefetch = [&](auto wc, auto qc, const char* xbase, const char* ybase) __attribute__((always_inline)) {
           constexpr int Q = decltype(qc)::value;
-          if constexpr (Q < 6) rd_x(xbase, wc, std::integral_constant<int, Q / 2>{}, std::integral_constant<int, Q % 2>{});
-          else rd_y(ybase, wc, std::integral_constant<int, Q - 6>{});
+          if constexpr (Q < 2 * KS) rd_x(xbase, wc, std::integral_constant<int, Q / 2>{}, std::integral_constant<int, Q % 2>{});
+          else rd_y(ybase, wc, std::integral_constant<int, Q - 2 * KS>{});
         };
         auto wrow = [&](auto wc, const char* by, const char* bx, char* oy, char* ox) __attribute__((always_inline)) {
-          constexpr int Wr = decltype(wc)::value;                     // window row 0 .. 9
-          constexpr int KLO = Wr - 2 < 0 ? 0 : Wr - 2, KHI = Wr < TH8 ? Wr : TH8 - 1;
-          constexpr int CNT = (KHI - KLO + 1) * 3;                    // MFMAs of this window row
-          constexpr int S0 = Wr == 0 ? 0 : Wr == 1 ? 3 : Wr <= 8 ? 9 * (Wr - 1) : 69;   // slots before it: 3, 6, then 9 per row, 6, 3
-          constexpr int NR = Wr + 1 > TH8 + 1 ? 0 : (Wr + 1 < TH8 ? 8 : 6);           // reads for window row Wr + 1 (dy rows end at 7)
+          constexpr int Wr = decltype(wc)::value;                     // window row 0 .. NWR - 1
+          constexpr int KLO = Wr - (KS - 1) < 0 ? 0 : Wr - (KS - 1), KHI = Wr < TH8 ? Wr : TH8 - 1;
+          constexpr int CNT = (KHI - KLO + 1) * KS;                   // MFMAs of this window row
+          constexpr int S0 = wrow_slots_before(Wr, KS, TH8);          // slots before it (3x3: 3, 6, then 9 per row, 6, 3)
+          constexpr int NR = Wr + 1 >= NWR ? 0 : (Wr + 1 < TH8 ? 2 * KS + 2 : 2 * KS);   // reads for window row Wr + 1 (dy rows end at 7)
           const char* xbase = bx + xa0;
           const char* ybase = by + ya0;
           auto one = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             if constexpr (j < CNT) {
-              constexpr int kk = KLO + j / 3, sft = j % 3, t = (Wr - kk) * 3 + sft;
+              // accumulator of (window row - output row, column shift): 3x3 taps ascend with the window offset, a ConvT parity's descend
+              constexpr int kk = KLO + j / KS, sft = j % KS, t = NTAPS == 9 ? (Wr - kk) * 3 + sft : (1 - (Wr - kk)) * 2 + (1 - sft);
               Tr<T>::mma(__builtin_bit_cast(uint4, ys[kk & 3]), __builtin_bit_cast(uint4, xs[Wr & 1][sft]), acc[t]);
               __builtin_amdgcn_sched_barrier(0);
               constexpr int R0 = j * NR / CNT, R1 = (j + 1) * NR / CNT;
@@ -364,21 +378,23 @@ __global__ __launch_bounds__(NTHR) void wgrad_mfma_kernel(const WgradArgs a, con
             rd_y(by + ya0, z, z); rd_y(by + ya0, z, o);
             rd_x(bx + xa0, z, z, z); rd_x(bx + xa0, z, z, o);
             rd_x(bx + xa0, z, o, z); rd_x(bx + xa0, z, o, o);
-            rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, z); rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, o);
+            if constexpr (KS == 3) { rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, z); rd_x(bx + xa0, z, std::integral_constant<int, 2>{}, o); }
           }
-          // loads of tile k+2 address the image through sg: bind it once the stores of tile k+1 (which only need scale / shift) are
-          // past -- the first load item sits in the second half of the tile (slot 36 = the first MFMA of window row 5)
+          // loads of tile k+2 address the image through sg: bind it before the first load item, which sits in the second half of the tile
+          // (3x3: slot 36 = the first MFMA of window row 5; 2x2: slot 16, inside window row 4) -- the stores of tile k+1 in the first
+          // half only need scale / shift
           wrow(std::integral_constant<int, 0>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 1>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 2>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 3>{}, by, bx, oy, ox);
+          if constexpr (KS == 2) sg.bind_image(tp2.n);
           wrow(std::integral_constant<int, 4>{}, by, bx, oy, ox);
-          sg.bind_image(tp2.n);
+          if constexpr (KS == 3) sg.bind_image(tp2.n);
           wrow(std::integral_constant<int, 5>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 6>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 7>{}, by, bx, oy, ox);
           wrow(std::integral_constant<int, 8>{}, by, bx, oy, ox);
-          wrow(std::integral_constant<int, 9>{}, by, bx, oy, ox);
+          if constexpr (NWR > 9) wrow(std::integral_constant<int, 9>{}, by, bx, oy, ox);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
           cur ^= 1;
@@ -485,7 +501,11 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   static const bool no_pipe2 = getenv("OCTSEG_NO_WGRAD_PIPE2") != nullptr;
   bool std33 = NTAPS == 9 && a.istride == 1 && a.span_x == 3 && a.span_y == 3;
   for (int t = 0; std33 && t < 9; ++t) std33 = a.tap_dy[t] - a.min_dy == t / 3 && a.tap_dx[t] - a.min_dx == t % 3;
-  if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && std33 && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
+  // ... and the 2x2 taps of one ConvTranspose2d parity (wgrad_launches' order: both offsets descending) over dy's parity plane
+  static const bool no_pipe2_4 = getenv("OCTSEG_NO_WGRAD_PIPE2_4") != nullptr;   // A/B switch
+  bool std22 = NTAPS == 4 && !no_pipe2_4 && a.istride == 1 && a.span_x == 2 && a.span_y == 2;
+  for (int t = 0; std22 && t < 4; ++t) std22 = a.tap_dy[t] - a.min_dy == 1 - t / 2 && a.tap_dx[t] - a.min_dx == 1 - t % 2;
+  if (!no_pipe2 && pipelined && th == 8 && dtype != DT_F32 && (std33 || std22) && 2 * lds <= 150 * 1024) { pipelined = 2; lds *= 2; }
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + th - 1) / th);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
   // One resident round at most (two workgroup slots per CU: 516 workgroups take twice as long as 504).  Every workgroup ends by

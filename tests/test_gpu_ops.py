@@ -63,6 +63,10 @@ CASES = [
     (3, 20, 20, 192, 64, 1, 1, 0, False),
     (2, 32, 32, 64, 128, 1, 1, 0, False),
     (1, 64, 80, 128, 384, 1, 1, 0, False),
+    # ConvTranspose2d weight gradient with all four output parities in one launch (wgrad_convt.hip, bf16): ragged 8 x 16 tiles of the
+    # low-resolution map (12 x 20), 1.5 ci tiles x 2.5 co tiles; and 60 tiles walked by split-K workgroups (window / plane double buffers)
+    (2, 12, 20, 96, 160, 4, 2, 1, True),
+    (4, 40, 48, 128, 64, 4, 2, 1, True),
 ]
 
 

@@ -28,8 +28,7 @@ MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 def _step(cuda, arch, enc, tied, S=128, B=2, classes=2, dtype=torch.bfloat16, probe=None):
     from oct_segmentation_amd.engine import SegNet, debug_tensor
     old = os.environ.pop('OCTSEG_TIED', None)
-    if tied:
-        os.environ['OCTSEG_TIED'] = tied
+    os.environ['OCTSEG_TIED'] = tied or '0'          # ('' = the plain path: the library's default ties the weight gradient)
     try:
         net = SegNet(arch, enc, classes=classes, device=cuda, compute_dtype=dtype, seed=5).train()
         img, mask = (t.to(cuda) for t in make_batch(B, classes, S, seed=9))
@@ -125,6 +124,18 @@ def test_tied_all_passes(cuda, arch, enc, probe):
     # (a perturbed forward moves ReLU masks: the same spread the bf16 engine shows against the fp32 oracle away from kink-free inputs)
     assert _cos(f0, f1) >= 0.97, f'global gradient cosine {_cos(f0, f1)}'
     assert torch.isfinite(f1).all()
+
+
+def test_tied_default_is_the_weight_gradient(cuda):
+    from oct_segmentation_amd.engine import SegNet
+    old = os.environ.pop('OCTSEG_TIED', None)
+    try:
+        net = SegNet('unet', 'resnet18', classes=1, device=cuda, compute_dtype=torch.bfloat16, seed=1)
+        alg, ex = net.fwd_macs(2, 64, 64), net.exec_macs(2, 64, 64)
+        assert ex[0] == alg and ex[1] == alg and ex[2] < alg
+    finally:
+        if old is not None:
+            os.environ['OCTSEG_TIED'] = old
 
 
 def test_tied_plan_needs_two_byte_dtype(cuda):

@@ -1,9 +1,11 @@
 #!/bin/bash
-# A/B of the tied decomposition on the default workload: per pass and all together (one JSON line each)
+# A/B of the tied decomposition on a bench workload: per pass and together (one summary line each).  usage: tied_ab.sh "<modes>" [bench args]
+modes=${1:-"- w dw fdw"}; shift
 out=gpurun_out/tied_ab.txt; : > $out
-for t in "" d w dw fdw; do
-  echo "== OCTSEG_TIED=$t" >> $out
-  OCTSEG_TIED=$t python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+for t in $modes; do
+  [ "$t" = "-" ] && t="0"
+  echo "== OCTSEG_TIED=$t $*" >> $out
+  OCTSEG_TIED=$t python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
