@@ -464,6 +464,12 @@ def main():
         tot_ms, tot_fl = sum(ms), sum(fl)
         peak = 2500.0 if args.dtype == 'bf16' else 157.3
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        ex = [e / B for e in net.exec_macs(B, S, S)]          # per frame: forward, data gradient, weight gradient
+        ex_fl = tot_fl - n_alone * B * 2.0 * sum(macs - e for e in ex)          # FLOPs the bracketed launches executed
+        ach_ex = ex_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        executed = {'gflop_per_frame': round(2 * sum(ex) / 1e9, 1), 'share_of_algorithmic': round(sum(ex) / (3 * macs), 4) if macs > 0 else 1.0,
+                    'achieved': round(ach_ex, 2), 'frac': round(ach_ex / peak, 4),
+                    'by_class_gflop_per_frame': {k: round(2 * e / 1e9, 1) for k, e in zip(('fwd', 'dgrad', 'wgrad'), ex)}}
         out = {
             'metric': f'OCT frames/sec ({S}x{S}, {args.dtype}) fwd+bwd',
             'value': round(frames / dt, 3),
@@ -491,6 +497,10 @@ def main():
                 'by_class': {k: {'ms_per_step': round(m / n_alone, 3), 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0}
                              for k, m, f in zip(('fwd', 'dgrad', 'wgrad'), ms, fl)},
                 'algorithmic_gflop_per_frame': round(6 * macs / 1e9, 1),
+                # `achieved` prices the reference graph's 6 x MACs.  Where the plan runs the decoder's nearest-x2 + 3x3 layers as a 4x4 stride-2
+                # kernel over the low-resolution map (same function of the same weights, 16 instead of 36 products per source pixel:
+                # octseg_plan_exec_macs) the matrix cores execute fewer FLOPs than that -- both are printed
+                'executed': executed,
                 'note': 'HIP-event brackets on the launch stream over an untimed pass of the same step with every launch on one '
                         'stream (octseg_debug_set_serial): the duration of each kernel alone; rocprofv3 summary of that mode: '
                         'profiles/r3_serial_kernel_stats.csv',

@@ -218,14 +218,18 @@ static void tied_dgrad_launches(const Geom& g, std::vector<ConvArgs>& out) {
 }
 
 static double layer_macs(const ConvLayer& L);
+// A/B switch: the tied data gradient as four 2x2-tap launches over dy's parity planes instead of one 16-tap stride-2 launch over dy
+static bool tie_dgrad_planes() { return getenv("OCTSEG_TIED_DGRAD_PLANES") != nullptr; }
 
-// OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie).  Default `w`:
-// the weight gradient is the same fp32 sum of the same bf16 products in another order, 16 instead of 36 of them per source pixel (U-Net++/
-// resnet101 16 x 704^2: weight-gradient class 21.7 -> 20.3 ms, profiles/r4_tied_ab.txt).  `f` and `d` are exact up to bf16 rounding and, on the
-// generic 4-tap loop, not faster yet -- opt-in.  OCTSEG_TIED=0 (or any string without f / d / w): none.
+// OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie).  Default `dw`.
+// The weight gradient is the same fp32 sum of the same bf16 products in another order, 16 instead of 36 of them per source pixel; the data
+// gradient contracts dy with the 4x4 image (sums of taps rounded to bf16 once) at the low resolution instead of with nine taps at the high one
+// followed by a 2x2 pool.  U-Net++/resnet101 16 x 704^2: weight-gradient class 21.4 -> 18.4 ms, data-gradient class 21.6 -> 20.1 ms
+// (profiles/r4_tied_ab.txt).  `f` is exact up to bf16 rounding too but not faster: four parity launches that add into the output plus a sweep
+// for the BatchNorm statistics -- opt-in.  OCTSEG_TIED=0 (or any string without f / d / w): none.
 static int tie_mask() {   // (read when a plan is built, so that one process can hold plans of both kinds)
   const char* e = getenv("OCTSEG_TIED");
-  if (e == nullptr) return 4;
+  if (e == nullptr) return 2 | 4;
   int v = 0;
   for (const char* c = e; *c; ++c) v |= *c == 'f' ? 1 : *c == 'd' ? 2 : *c == 'w' ? 4 : 0;
   return v;
@@ -1215,7 +1219,8 @@ static int build_plan(octseg_plan* P) {
         fwd_launches(gu, v);
         L.tie_pk_fu = conv_pack_info(v[0], P->dtype);
         L.tie_fu_off = off; off += align_up(conv_image_bytes(L.tie_pk_fu, 16));
-        v.clear(); tied_dgrad_launches(gu, v);
+        v.clear();
+        if (tie_dgrad_planes()) tied_dgrad_launches(gu, v); else dgrad_launches(gu, v);
         L.tie_pk_du = conv_pack_info(v[0], P->dtype);
         L.tie_du_off = off; off += align_up(conv_image_bytes(L.tie_pk_du, 16));
         if (Cs > 0) {
@@ -2020,21 +2025,22 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     const TensorInfo& t0 = P->tensors[ti0];
     const double macs = layer_macs(L);
     std::vector<ConvArgs> lu;
-    tied_dgrad_launches(tie_geom_up(L), lu);
+    const bool planes = tie_dgrad_planes();
+    if (planes) tied_dgrad_launches(tie_geom_up(L), lu); else dgrad_launches(tie_geom_up(L), lu);   // (one launch: 16 taps at stride 2 over dy)
     const int acc0 = E.claim(ti0);
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < (int)lu.size(); ++k) {
       ConvArgs& a = lu[k];
       const int py = k >> 1, px = k & 1;
       SrcDesc s;
-      s.ptr = (const char*)dy + ((size_t)py * L.OW + px) * dyC * esz;
-      s.scale = nullptr; s.shift = nullptr; s.C = 2 * dyC; s.c0 = 0; s.H = L.OH / 2; s.W = L.OW; s.up = 0; s.relu = 0;
+      s.ptr = (const char*)dy + (planes ? ((size_t)py * L.OW + px) * dyC * esz : 0);
+      s.scale = nullptr; s.shift = nullptr; s.C = planes ? 2 * dyC : dyC; s.c0 = 0; s.H = planes ? L.OH / 2 : L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
       a.src[0] = s; a.nsrc = 1;
       a.Cin = L.Cout;
       a.W = E.ws + L.tie_du_off;
       DstDesc d;
       d.ptr = E.grad(ti0); d.C = t0.C; d.c0 = 0; d.cn = L.tie_Ca; d.H = t0.H; d.W = t0.W; d.accum = k == 0 ? acc0 : 1; d.pool = 0;
       a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
-      ProfScope ps(1, 2.0 * macs * L.tie_Ca / L.Cin / 4.0, E.st, L.name);
+      ProfScope ps(1, 2.0 * macs * L.tie_Ca / L.Cin / (double)lu.size(), E.st, L.name);
       HIPCHK(launch_conv(P->dtype, a, E.st));
     }
     if (L.tie_Cs > 0) {
