@@ -489,7 +489,7 @@ def main():
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3),
             'power': power,
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + conv3x3p_kernel + gemm1x1_kernel + thin_conv_kernel + wgrad_mfma_kernel + wgrad1x1_kernel + thin_wgrad_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel + conv3x3p_kernel + gemm1x1_kernel + thin_conv_kernel + wgrad_mfma_kernel + wgrad1x1_kernel + wgrad_convt16_kernel + thin_wgrad_kernel (implicit-GEMM conv fwd / dgrad / wgrad)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                 'launches_per_step': round(sum(nl) / n_alone, 1),
                 'avg_launch_ms': round(tot_ms / max(1.0, sum(nl)), 4),

@@ -21,7 +21,7 @@ for k in res['FETCH_SIZE']:
     f_kib, n = res['FETCH_SIZE'][k]
     w_kib, _ = res['WRITE_SIZE'].get(k, (0.0, n))
     rows[k] = {'launches': n, 'fetch_bytes_per_launch': 2.0 * f_kib * 1024 / n, 'write_bytes_per_launch': w_kib * 1024 / n}
-FAMILY = ('conv_mfma_kernel', 'conv3x3p_kernel', 'wgrad_mfma_kernel', 'wgrad1x1_kernel', 'gemm1x1_kernel', 'thin_conv_kernel', 'thin_wgrad_kernel')
+FAMILY = ('conv_mfma_kernel', 'conv3x3p_kernel', 'wgrad_mfma_kernel', 'wgrad1x1_kernel', 'wgrad_convt16_kernel', 'gemm1x1_kernel', 'thin_conv_kernel', 'thin_wgrad_kernel')
 conv = {k: v for k, v in rows.items() if any(f in k for f in FAMILY)}
 tot_l = sum(v['launches'] for v in conv.values())
 summary = {'kernels': rows,
