@@ -73,6 +73,12 @@ struct ConvArgs {
   const float* Wmaster;
   int wO, wI, wtrans;
   const float* wscale;
+  // Per-source tap subsets (0: every source meets every tap).  taps_per_src = n > 0: the K chunks of source i only contract with the n taps
+  // whose indices are packed four bits each in src_taps[i] -- ConvTranspose2d's data gradient as ONE stride-1 launch over dy's four parity
+  // planes (each plane a source of its own, a view of dy with doubled strides), every plane with its own 2 x 2 of the 3 x 3 tap offsets.
+  // Sources must start on K-chunk boundaries; routed to conv_mfma_kernel's masked loop.
+  int taps_per_src;
+  int src_taps[MAX_SRC];
 };
 
 struct WgradArgs {

@@ -500,7 +500,8 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 // budget of the largest loop):  0 rolled tap loop (any tap table)   1 resident taps (one K chunk, small slabs)
 //                               2 1x1 (one tap, four window passes per chunk)   3 run9r (3x3, slab ring)
 //                               4 run9s (3x3, ONE K chunk: slab ring only -- the K-thin data gradients of the decoder)
-enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4 };
+//                               5 masked (per-source tap subsets, ConvArgs::taps_per_src: the rolled loop over each chunk's own taps, two window passes per tap)
+enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4, LOOP_MASKED = 5 };
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 2) ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
@@ -768,6 +769,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
     if (resident) {
       for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
+    } else if constexpr (LOOP == LOOP_MASKED) {
+      dmaB(a.tap_w[a.src_taps[0] & 15] * nchunks, 0);   // first tap of the first source's list
     } else {
       dmaB(a.tap_w[0] * nchunks, 0);
       if constexpr (LOOP == LOOP_RUN9 || LOOP == LOOP_RUN9S) dmaB(a.tap_w[1] * nchunks, 1);   // three-slot ring: two slabs ahead
@@ -860,6 +863,63 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
           stage_full(nxt, ldsA);
           __syncthreads();
         }
+      }
+    }
+  };
+  // Per-source tap subsets (ConvArgs::taps_per_src): `run` with the tap loop walking the list of the source that owns the chunk -- four taps
+  // per 64-channel chunk instead of nine, so the next chunk's window (six passes) is prefetched two passes per tap.  Host-checked: double-
+  // buffered window, sources on chunk boundaries, npass <= 2 * taps_per_src.
+  auto run_masked = [&](auto ppt_c) {
+    constexpr int PPT = decltype(ppt_c)::value;
+    const int tps = a.taps_per_src;
+    auto list_of = [&](int chunk) -> int {
+      int l = a.src_taps[0];
+#pragma unroll
+      for (int i = 1; i < MAX_SRC; ++i)
+        if (i < a.nsrc && chunk * KC >= a.src[i].c0) l = a.src_taps[i];
+      return l;
+    };
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool has_next = chunk + 1 < nchunks;
+      const int cnext = has_next ? chunk + 1 : chunk;
+      Stager nxt;
+      nxt.setup(a.src, a.nsrc, a.Cin, cnext, tid, a.src_uniform != 0);
+      nxt.bind_image(n);
+      const char* awin = ldsA + ((chunk & 1) ? abytes : 0);
+      char* anext = ldsA + ((chunk & 1) ? 0 : abytes);
+      const int lst = list_of(chunk), lst_n = list_of(cnext);
+      int hy = hy_first, hx = hx_first, hp = p0w;
+      char* wrow = anext + p0w * PITCH;
+      for (int k = 0; k < tps; ++k, ++it) {
+        const int t = (lst >> (4 * k)) & 15;
+        uint4 av[PPT];
+        bool aok[PPT];
+        char* wr[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+          av[u] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[u]);
+          wr[u] = wrow;
+          const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+          if (adv) {
+            hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
+            hy += dq; hx += dr;
+            if (hx >= RW) { hx -= RW; hy += 1; }
+          }
+        }
+        // slab of the next iteration: the next tap of this chunk's list, or the first of the next chunk's
+        const bool same = k + 1 < tps;
+        const int tn = same ? (lst >> (4 * (k + 1))) & 15 : lst_n & 15;
+        dmaB(__builtin_amdgcn_readlane(v_tapw, tn) * nchunks + (same ? chunk : cnext), (it + 1) & 1);
+        const int toff = __builtin_amdgcn_readlane(v_toff, t);
+        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) nxt.write_at(wr[u], av[u], aok[u]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
     }
   };
@@ -1118,6 +1178,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     }
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
     if constexpr (NDMA % NWAVES == 0 && (RB == 128 || (RB == 64 && NT == 4))) run9r();
+  } else if constexpr (LOOP == LOOP_MASKED) {   // host-checked: dbuf, per-source tap lists, npass <= 2 * taps_per_src
+    run_masked(std::integral_constant<int, 2>{});
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
     run1p();   // (the rolled loop is not kept as an A/B switch here: with both in one function hipcc moved the by-value ConvArgs to scratch)
   } else {
@@ -1187,6 +1249,9 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
     case LOOP_RUN9S:
       if constexpr (RB == 128 && ((NT * 32 * WN * RB / 1024) % (WM * WN)) == 0) return launch_loop<T, NT, WN, WM, RB, LOOP_RUN9S>(a, mode, lds, st);
       else return hipErrorInvalidValue;
+    case LOOP_MASKED:
+      if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_MASKED>(a, mode, lds, st);
+      else return hipErrorInvalidValue;
     default: return launch_loop<T, NT, WN, WM, RB, LOOP_GENERIC>(a, mode, lds, st);
   }
 }
@@ -1198,6 +1263,16 @@ struct Choice { Variant v; int dbuf; size_t lds; int resident; int ring3; int ri
 static Choice choose(const ConvArgs& a, int esz) {
   Choice c;
   c.ring3 = 0; c.ring1 = 0;
+  if (a.taps_per_src > 0) {   // masked loop: the 128-channel N tile, 64-channel chunks, double-buffered window (conv_masked_eligible checked the rest)
+    for (int wm = 4; wm >= 2; wm -= 2) {
+      const Variant v{2, 2, wm, 128};
+      int npass = 0;
+      const size_t lds = variant_lds(a, v, esz, 1, &npass);
+      if (lds <= (size_t)160 * 1024 && npass <= 2 * a.taps_per_src) { c.v = v; c.dbuf = 1; c.lds = lds; c.resident = 0; return c; }
+    }
+    c.v = Variant{2, 2, 2, 128}; c.dbuf = 1; c.resident = 0; c.lds = (size_t)1 << 30;   // (never launched: dispatch refuses)
+    return c;
+  }
   // Wide-N configuration for the 3x3 layers with >= 256 output channels (54 % of U-Net++/resnet101's FLOPs: x_1_2, x_2_2, x_1_1,
   // x_0_0 and the data gradients of the wide concat layers): 16x16 pixels x 256 channels per workgroup, 4 waves of 128 pixels x
   // 128 channels (256 accumulators each: one wave per SIMD owns the whole register file), 64-byte K chunks.  Against the 128-channel tile the staged window serves twice the
@@ -1331,7 +1406,8 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
     static const bool no_usrc = getenv("OCTSEG_NO_UNIFORM_SRC") != nullptr;   // A/B switch
     if (no_usrc) a.src_uniform = 0;
   }
-  const int loop = c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
+  const int loop = a.taps_per_src > 0 ? LOOP_MASKED
+                   : c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
     return launch_variant<T, NT_, WN_, WM_, RB_>(a, c.dbuf, loop, c.lds, st);
@@ -1398,8 +1474,27 @@ int conv_num_mtiles_flat(const ConvArgs& a0, int dtype) {
   return conv_num_mtiles(a, dtype);
 }
 
+// what the masked loop needs of a launch with per-source tap subsets (the plan falls back to its other form when this says no)
+bool conv_masked_eligible(const ConvArgs& a, int dtype) {
+  static const bool off = getenv("OCTSEG_NO_MASKED_LOOP") != nullptr;   // A/B switch
+  if (off || dtype == DT_F32 || a.taps_per_src <= 0 || a.taps_per_src > 8 || a.ntaps < 2 || a.ntaps > 16) return false;
+  if (a.istride != 1 || a.ostride != 1 || a.out_mode == OUT_HEAD_NCHW || a.Cout <= 64 || a.Cout % 8 != 0) return false;
+  const int KC = 64;
+  for (int i = 0; i < a.nsrc; ++i)
+    if (a.src[i].c0 % KC != 0 || a.src[i].up) return false;
+  if (a.Cin % KC != 0) return false;
+  const Choice c = choose(a, (int)dtype_size(dtype));
+  return c.lds <= (size_t)160 * 1024;
+}
+
 hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t st) {
   if (a0.ntaps <= 0) return hipSuccess;
+  if (a0.taps_per_src > 0) {
+    if (!conv_masked_eligible(a0, dtype)) return hipErrorInvalidValue;
+    ConvArgs a = a0;
+    a.tile_order = 1;
+    return dtype == DT_F16 ? dispatch<f16_t>(a, st) : dispatch<bf16_t>(a, st);
+  }
   if (thin_conv_eligible(a0, dtype)) return launch_thin_conv(dtype, a0, st);
   if (gemm1x1_eligible(a0, dtype)) return launch_gemm1x1(dtype, a0, st);
   if (conv3x3p_eligible(a0, dtype)) return launch_conv3x3p(dtype, a0, st);

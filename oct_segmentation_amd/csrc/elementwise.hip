@@ -1148,7 +1148,17 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char
     for (int i = 0; i < VEC; ++i) {
       const int c = c0 + i;
       float val = 0.f;
-      if (co < rows && c < K) {
+      if (jb.tied == 2) {
+        // data-gradient image of the masked parity-plane launch: rows = input channels, K = 4 O virtual channels (plane p = c / O), nine
+        // tap offsets: plane (py, px) at offset (dy, dx) carries kernel tap r = py + 1 + 2 dy, s = px + 1 + 2 dx where that exists
+        if (co < jb.I && c < 4 * jb.O) {
+          const int p = c / jb.O, o = c - p * jb.O;
+          const int u = (p >> 1) + 1 + 2 * (tap / 3 - 1), vv = (p & 1) + 1 + 2 * (tap % 3 - 1);
+          if (u >= 0 && u <= 3 && vv >= 0 && vv <= 3)
+            for (int r3 = max(0, 2 - u); r3 <= min(2, 3 - u); ++r3)
+              for (int s3 = max(0, 2 - vv); s3 <= min(2, 3 - vv); ++s3) val += w[((size_t)(r3 * 3 + s3) * jb.O + o) * sI + co + jb.src_c0];
+        }
+      } else if (co < rows && c < K) {
         const int o = jb.transpose ? c : co, ci = (jb.transpose ? co : c) + jb.src_c0;
         if (!jb.tied) val = w[((size_t)tap * jb.O + o) * sI + ci];
         else {   // 4x4 stride-2 kernel of (nearest x2, then the 3x3 source): the source taps that land on the same low-resolution pixel, summed in f32

@@ -15,6 +15,7 @@ static inline size_t conv_image_bytes(const ConvPackInfo& p, int wtaps) {
   return (size_t)wtaps * p.nchunks * p.ntiles * p.BN * p.RB;
 }
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
+bool conv_masked_eligible(const ConvArgs& a, int dtype);   // launches with per-source tap subsets (ConvArgs::taps_per_src): can the masked loop take this one?
 
 // gemm1x1.hip: stride-1, single-source 1x1 convs and their data gradients as a persistent GEMM (2-byte dtypes); consumes the same
 // packed weight image as conv_mfma_kernel.  launch_conv routes eligible launches there; its BN-stat slab has one row per
@@ -236,7 +237,8 @@ struct PackJob { size_t src_off /*floats*/, dst_off /*bytes*/; int taps, O, I, t
                                       forward image when packing for eval (~0: none) */
                  int src_I;        /* row length of the SOURCE weight when the image covers a channel slice of it (0: I) */
                  int src_c0;       /* first source channel of that slice */
-                 int tied;         /* 1: taps == 16, the image is the 4x4 stride-2 kernel that a nearest-x2 upsample followed by the 3x3
+                 int tied;         /* 2: the masked data-gradient image of the same kernel (taps == 9 offsets, K = 4 O: dy's four parity planes);
+                                      1: taps == 16, the image is the 4x4 stride-2 kernel that a nearest-x2 upsample followed by the 3x3
                                          source is equal to: K4[u][v] = sum of W3[r][s] over r in A(u), s in A(v), A(k) = [max(0, 2 - k), min(2, 3 - k)] */ };
 // gradient of the tied image back into the 3x3 weight it was derived from: dW3[t][o][i] += (i < Ca ? sum of dK4 over the (u, v) whose
 // A(u) x A(v) holds tap t : dW3s[t][o][i - Ca]);  dK4 [16][O][Ca], dW3s [9][O][Cs] (nullptr when Cs == 0), dW3 [9][O][Ca + Cs], all f32

@@ -221,6 +221,31 @@ static double layer_macs(const ConvLayer& L);
 // A/B switch: the tied data gradient as four 2x2-tap launches over dy's parity planes instead of one 16-tap stride-2 launch over dy
 static bool tie_dgrad_planes() { return getenv("OCTSEG_TIED_DGRAD_PLANES") != nullptr; }
 
+// ... and as ONE stride-1 launch whose four sources are dy's parity planes (virtual channels [p O, (p + 1) O) = plane p), every plane contracting
+// with its own 2 x 2 of the 3 x 3 tap offsets (ConvArgs::taps_per_src, conv_mfma.hip's masked loop): plane (py, px) at offset (dy, dx) carries
+// kernel tap r = py + 1 + 2 dy, s = px + 1 + 2 dx where that lies in [0, 3].  Sources (pointers, strides) are filled by the caller.
+static void tied_dgrad_masked(const Geom& g, ConvArgs& a) {
+  memset(&a, 0, sizeof(a));
+  int n = 0;
+  for (int t = 0; t < 9; ++t) { a.tap_dy[n] = t / 3 - 1; a.tap_dx[n] = t % 3 - 1; a.tap_w[n] = t; ++n; }
+  set_taps(a.tap_dy, a.tap_dx, a.tap_w, n, a.ntaps, a.min_dy, a.min_dx, a.span_y, a.span_x);
+  a.istride = 1; a.N = g.N; a.IH = g.IH; a.IW = g.IW; a.OH = g.IH; a.OW = g.IW;
+  a.Cin = 4 * g.Cout; a.Cout = g.Cin; a.ostride = 1;
+  a.taps_per_src = 4; a.nsrc = 4;
+  for (int p = 0; p < 4; ++p) {
+    const int py = p >> 1, px = p & 1;
+    int list = 0, k = 0;
+    for (int t = 0; t < 9; ++t) {
+      const int r = py + 1 + 2 * (t / 3 - 1), s = px + 1 + 2 * (t % 3 - 1);
+      if (r >= 0 && r <= 3 && s >= 0 && s <= 3) list |= t << (4 * k++);
+    }
+    a.src_taps[p] = list;
+    SrcDesc d{};
+    d.C = 2 * g.Cout; d.c0 = p * g.Cout; d.H = g.IH; d.W = 2 * g.IW;
+    a.src[p] = d;
+  }
+}
+
 // OCTSEG_TIED=[f][d][w]: which passes of the decoder's (nearest x2, concat, 3x3) layers run the tied decomposition (ConvLayer::tie).  Default `dw`.
 // The weight gradient is the same fp32 sum of the same bf16 products in another order, 16 instead of 36 of them per source pixel; the data
 // gradient contracts dy with the 4x4 image (sums of taps rounded to bf16 once) at the low resolution instead of with nine taps at the high one
@@ -1220,9 +1245,16 @@ static int build_plan(octseg_plan* P) {
         L.tie_pk_fu = conv_pack_info(v[0], P->dtype);
         L.tie_fu_off = off; off += align_up(conv_image_bytes(L.tie_pk_fu, 16));
         v.clear();
-        if (tie_dgrad_planes()) tied_dgrad_launches(gu, v); else dgrad_launches(gu, v);
+        L.tie_du_masked = false;
+        if (!tie_dgrad_planes() && L.Cout % 64 == 0) {   // one masked launch over the four parity planes: the planes are whole K chunks
+          ConvArgs am;
+          tied_dgrad_masked(gu, am);
+          DstDesc dd{}; dd.H = gu.IH; dd.W = gu.IW; dd.C = Ca; dd.cn = Ca; am.dst[0] = dd; am.ndst = 1;
+          if (conv_masked_eligible(am, P->dtype)) { L.tie_du_masked = true; v.push_back(am); }
+        }
+        if (!L.tie_du_masked) { if (tie_dgrad_planes()) tied_dgrad_launches(gu, v); else dgrad_launches(gu, v); }
         L.tie_pk_du = conv_pack_info(v[0], P->dtype);
-        L.tie_du_off = off; off += align_up(conv_image_bytes(L.tie_pk_du, 16));
+        L.tie_du_off = off; off += align_up(conv_image_bytes(L.tie_pk_du, L.tie_du_masked ? 9 : 16));
         if (Cs > 0) {
           v.clear(); fwd_launches(gs, v);
           L.tie_pk_fs = conv_pack_info(v[0], P->dtype);
@@ -1288,7 +1320,7 @@ static int build_plan(octseg_plan* P) {
         P->pack_total += (unsigned long long)ntaps * pk.nchunks * pk.ntiles * pk.BN * (pk.RB / 16);
       };
       add(L.tie_fu_off, 16, L.tie_Ca, 0, 0, 1, L.tie_pk_fu);
-      add(L.tie_du_off, 16, L.tie_Ca, 0, 1, 1, L.tie_pk_du);
+      add(L.tie_du_off, L.tie_du_masked ? 9 : 16, L.tie_Ca, 0, 1, L.tie_du_masked ? 2 : 1, L.tie_pk_du);
       if (L.tie_Cs > 0) {
         add(L.tie_fs_off, 9, L.tie_Cs, L.tie_Ca, 0, 0, L.tie_pk_fs);
         add(L.tie_ds_off, 9, L.tie_Cs, L.tie_Ca, 1, 0, L.tie_pk_ds);
@@ -2025,17 +2057,27 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     const TensorInfo& t0 = P->tensors[ti0];
     const double macs = layer_macs(L);
     std::vector<ConvArgs> lu;
-    const bool planes = tie_dgrad_planes();
-    if (planes) tied_dgrad_launches(tie_geom_up(L), lu); else dgrad_launches(tie_geom_up(L), lu);   // (one launch: 16 taps at stride 2 over dy)
+    const bool planes = tie_dgrad_planes() && !L.tie_du_masked;
+    if (L.tie_du_masked) { lu.resize(1); tied_dgrad_masked(tie_geom_up(L), lu[0]); }
+    else if (planes) tied_dgrad_launches(tie_geom_up(L), lu);
+    else dgrad_launches(tie_geom_up(L), lu);   // (one launch: 16 taps at stride 2 over dy)
     const int acc0 = E.claim(ti0);
     for (int k = 0; k < (int)lu.size(); ++k) {
       ConvArgs& a = lu[k];
       const int py = k >> 1, px = k & 1;
-      SrcDesc s;
-      s.ptr = (const char*)dy + (planes ? ((size_t)py * L.OW + px) * dyC * esz : 0);
-      s.scale = nullptr; s.shift = nullptr; s.C = planes ? 2 * dyC : dyC; s.c0 = 0; s.H = planes ? L.OH / 2 : L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
-      a.src[0] = s; a.nsrc = 1;
-      a.Cin = L.Cout;
+      if (L.tie_du_masked) {
+        for (int p = 0; p < 4; ++p) {   // plane p of dy as a tensor of its own: first pixel (p >> 1, p & 1), doubled pixel and row strides
+          SrcDesc& s = a.src[p];
+          s.ptr = (const char*)dy + ((size_t)(p >> 1) * L.OW + (p & 1)) * dyC * esz;
+          s.scale = nullptr; s.shift = nullptr; s.C = 2 * dyC; s.c0 = p * L.Cout; s.H = L.OH / 2; s.W = L.OW; s.up = 0; s.relu = 0;
+        }
+      } else {
+        SrcDesc s;
+        s.ptr = (const char*)dy + (planes ? ((size_t)py * L.OW + px) * dyC * esz : 0);
+        s.scale = nullptr; s.shift = nullptr; s.C = planes ? 2 * dyC : dyC; s.c0 = 0; s.H = planes ? L.OH / 2 : L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
+        a.src[0] = s; a.nsrc = 1;
+        a.Cin = L.Cout;
+      }
       a.W = E.ws + L.tie_du_off;
       DstDesc d;
       d.ptr = E.grad(ti0); d.C = t0.C; d.c0 = 0; d.cn = L.tie_Ca; d.H = t0.H; d.W = t0.W; d.accum = k == 0 ? acc0 : 1; d.pool = 0;

@@ -80,6 +80,7 @@ struct ConvLayer {
   int tie = 0, tie_Ca = 0, tie_Cs = 0;
   size_t tie_fu_off = 0, tie_fs_off = 0, tie_du_off = 0, tie_ds_off = 0;   // images: forward up / skip, data gradient up / skip
   ConvPackInfo tie_pk_fu, tie_pk_fs, tie_pk_du, tie_pk_ds;
+  bool tie_du_masked = false;   // the data gradient over the upsampled source's channels is ONE masked launch over dy's parity planes (9-tap image, 4 O virtual channels)
 };
 
 enum OpKind { OP_STEM_COL, OP_CONV, OP_BN_FIN, OP_BN_ACT, OP_MAXPOOL,
