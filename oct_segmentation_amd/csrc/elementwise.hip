@@ -541,8 +541,12 @@ hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t st) {
 }
 
 // dy = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+// MM = how the ReLU mask is found (0 none, 1 recomputed from y, 2 from the stored activation, 3 from bn_act's bit planes): a template parameter
+// so that each variant only keeps its own operands in registers, and at most 128 of them (four waves per SIMD, launch bound): the weight-gradient
+// kernels on the side stream hold 380-384 of a SIMD's 512 registers per lane for a whole launch, and a sweep wave that needs more than the
+// remaining 128 cannot start beside them -- the sweep then waits for compute units instead of hiding under the matrix work.
+template <typename T, int MM>
+__global__ __launch_bounds__(256, 4) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   constexpr int VEC = EV<T>::VEC;
   const int vpc = a.C / VEC;
   const size_t nvec = a.npix * (size_t)vpc;
@@ -562,14 +566,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   for (size_t vb = v0; vb < nvec; vb += U * stride) {
     uint4 gv[U], yv[U], ov[U];
     unsigned mb[U];
-    const bool use_bits = a.mask == 2 && a.maskbits != nullptr;
+    constexpr bool use_bits = MM == 3;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t v = vb + u * stride < nvec ? vb + u * stride : vb;
       gv[u] = ldv<T>(a.g, v); yv[u] = ldv<T>(a.y, v);
       mb[u] = 0;
       if (use_bits) mb[u] = a.maskbits[v];
-      else if (a.mask == 2) ov[u] = ldv<T>(a.out, v);
+      else if (MM == 2) ov[u] = ldv<T>(a.out, v);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -581,12 +585,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
       if (use_bits) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) if (!((mb[u] >> i) & 1u)) g[i] = 0.f;
-      } else if (a.mask == 2) {
+      } else if (MM == 2) {
         float o[VEC];
         EV<T>::unpack(ov[u], o);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) if (!(o[i] > 0.f)) g[i] = 0.f;
-      } else if (a.mask == 1) {
+      } else if (MM == 1) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) if (!(fmaf(y[i], sc[i], sh[i]) > 0.f)) g[i] = 0.f;
       }
@@ -616,8 +620,14 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
   const int vpc = a.C / (dtype == DT_F32 ? 4 : 8);
   const size_t nvec = a.npix * (size_t)vpc;
   const int g = grid_for_channels(nvec, vpc);
-  if (dtype == DT_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, a);
+  const int mm = a.mask == 2 ? (a.maskbits != nullptr ? 3 : 2) : a.mask;
+#define OCTSEG_APPLY(MM_)                                                                                             \
+  if (mm == MM_) {                                                                                                    \
+    if (dtype == DT_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, MM_>), dim3(g), dim3(256), 0, st, a);         \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, MM_>), dim3(g), dim3(256), 0, st, a);                        \
+  }
+  OCTSEG_APPLY(0) OCTSEG_APPLY(1) OCTSEG_APPLY(2) OCTSEG_APPLY(3)
+#undef OCTSEG_APPLY
   return hipGetLastError();
 }
 

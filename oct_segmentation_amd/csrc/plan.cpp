@@ -1981,198 +1981,212 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
     HIPCHK(launch_stem_im2col(P->dtype, P->stem_image, E.act(P->col_tensor), P->B, P->H, P->W, tc.C, P->stem_mean, P->stem_std,
                               P->stem_normalize, ws_));
   }
-  // weight gradient (+ bias gradient) on the side stream: fork after everything that produced dy
-  hipStream_t ws_ = E.wst ? E.wst : E.st;
-  if (ws_ != E.st) {
-    HIPCHK(hipEventRecord(P->ev_fork, E.st));
-    HIPCHK(hipStreamWaitEvent(ws_, P->ev_fork, 0));
-  }
-  // bias gradient
-  if (L.b >= 0)
-    HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, ws_));
-  if (L.tie & 4) {
-    // tied: gradient of the 4x4 image (low-resolution source x dy's parity planes) and of the skip slice's 3x3 into scratch, folded into the
-    // 3x3 gradient by one sweep (the side stream runs the layers one after the other: one scratch serves them all)
-    SrcDesc src[MAX_SRC];
-    const int ns = E.fill_srcs(L, src);
-    const int Ca = L.tie_Ca, Cs = L.tie_Cs;
-    float* dK4 = (float*)(E.ws + P->tie_scratch_off);
-    float* dW3s = dK4 + (size_t)16 * L.Cout * Ca;
-    HIPCHK(hipMemsetAsync(dK4, 0, ((size_t)16 * Ca + (size_t)9 * Cs) * L.Cout * sizeof(float), ws_));
-    const double macs = layer_macs(L);
-    std::vector<WgradArgs> lw;
-    wgrad_launches(tie_geom_up(L), lw);
-    for (auto& a : lw) {
-      a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
-      a.dy = dy; a.dyC = dyC; a.dW = dK4; a.stamp = nullptr;
+  // The weight gradient depends on dy and on saved activations only: forked in front of the layer's data gradient.  OCTSEG_WGRAD_BEHIND (A/B):
+  // forked behind it, so that it would start together with the BatchNorm sweeps of the layer below (HBM-bound; at <= 128 registers they fit
+  // beside its one-wave-per-SIMD workgroups) -- measured 70.2 against 68.5 ms per step (round 4, ABAB on one box; round 2: 78.8 against 78.4):
+  // the side stream then idles through every data gradient's first half and the step's tail grows.
+  static const bool wgrad_first = getenv("OCTSEG_WGRAD_BEHIND") == nullptr;
+  auto wgrad_part = [&]() -> int {
+    // weight gradient (+ bias gradient) on the side stream: fork after everything that produced dy
+    hipStream_t ws_ = E.wst ? E.wst : E.st;
+    if (ws_ != E.st) {
+      HIPCHK(hipEventRecord(P->ev_fork, E.st));
+      HIPCHK(hipStreamWaitEvent(ws_, P->ev_fork, 0));
     }
-    if (wgrad_convt16_eligible(lw[0], P->dtype)) {   // all four parities from one staged window (wgrad_convt.hip)
-      ProfScope ps(2, 2.0 * macs * Ca / L.Cin, ws_, L.name);
-      HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
-    } else {
+    // bias gradient
+    if (L.b >= 0)
+      HIPCHK(launch_channel_sum(P->dtype, dy, (size_t)L.N * L.OH * L.OW, dyC, L.Cout, E.grads + P->params[L.b].off, ws_));
+    if (L.tie & 4) {
+      // tied: gradient of the 4x4 image (low-resolution source x dy's parity planes) and of the skip slice's 3x3 into scratch, folded into the
+      // 3x3 gradient by one sweep (the side stream runs the layers one after the other: one scratch serves them all)
+      SrcDesc src[MAX_SRC];
+      const int ns = E.fill_srcs(L, src);
+      const int Ca = L.tie_Ca, Cs = L.tie_Cs;
+      float* dK4 = (float*)(E.ws + P->tie_scratch_off);
+      float* dW3s = dK4 + (size_t)16 * L.Cout * Ca;
+      HIPCHK(hipMemsetAsync(dK4, 0, ((size_t)16 * Ca + (size_t)9 * Cs) * L.Cout * sizeof(float), ws_));
+      const double macs = layer_macs(L);
+      std::vector<WgradArgs> lw;
+      wgrad_launches(tie_geom_up(L), lw);
       for (auto& a : lw) {
-        ProfScope ps(2, 2.0 * macs * Ca / L.Cin / 4.0, ws_, L.name);
+        a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
+        a.dy = dy; a.dyC = dyC; a.dW = dK4; a.stamp = nullptr;
+      }
+      if (wgrad_convt16_eligible(lw[0], P->dtype)) {   // all four parities from one staged window (wgrad_convt.hip)
+        ProfScope ps(2, 2.0 * macs * Ca / L.Cin, ws_, L.name);
+        HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
+      } else {
+        for (auto& a : lw) {
+          ProfScope ps(2, 2.0 * macs * Ca / L.Cin / 4.0, ws_, L.name);
+          HIPCHK(launch_wgrad(P->dtype, a, ws_));
+        }
+      }
+      if (Cs > 0) {
+        lw.clear();
+        wgrad_launches(tie_geom_skip(L), lw);
+        WgradArgs& a = lw[0];
+        a.nsrc = ns - 1;
+        for (int i = 1; i < ns; ++i) { a.src[i - 1] = src[i]; a.src[i - 1].c0 -= Ca; }
+        a.dy = dy; a.dyC = dyC; a.dW = dW3s; a.stamp = nullptr;
+        ProfScope ps(2, 2.0 * macs * Cs / L.Cin, ws_, L.name);
+        HIPCHK(launch_wgrad(P->dtype, a, ws_));
+      }
+      HIPCHK(launch_tied_fold(dK4, Cs > 0 ? dW3s : nullptr, E.grads + P->params[L.w].off, L.Cout, Ca, Cs, ws_));
+    } else {
+      std::vector<WgradArgs> lw;
+      wgrad_launches(g, lw);
+      for (auto& a : lw) {
+        a.nsrc = E.fill_srcs(L, a.src);
+        a.dy = dy; a.dyC = dyC;
+        a.dW = E.grads + P->params[L.w].off;
+        a.stamp = nullptr;
+      }
+      if (L.transposed && lw.size() == 4 && wgrad_convt16_eligible(lw[0], P->dtype)) {   // ConvTranspose2d: the four parities in one launch
+        ProfScope ps(2, 2.0 * layer_macs(L), ws_, L.name);
+        HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
+        lw.clear();
+      }
+      const double nl = (double)lw.size();
+      for (auto& a : lw) {
+        ProfScope ps(2, 2.0 * layer_macs(L) / nl, ws_, L.name);
         HIPCHK(launch_wgrad(P->dtype, a, ws_));
       }
     }
-    if (Cs > 0) {
-      lw.clear();
-      wgrad_launches(tie_geom_skip(L), lw);
-      WgradArgs& a = lw[0];
-      a.nsrc = ns - 1;
-      for (int i = 1; i < ns; ++i) { a.src[i - 1] = src[i]; a.src[i - 1].c0 -= Ca; }
-      a.dy = dy; a.dyC = dyC; a.dW = dW3s; a.stamp = nullptr;
-      ProfScope ps(2, 2.0 * macs * Cs / L.Cin, ws_, L.name);
-      HIPCHK(launch_wgrad(P->dtype, a, ws_));
-    }
-    HIPCHK(launch_tied_fold(dK4, Cs > 0 ? dW3s : nullptr, E.grads + P->params[L.w].off, L.Cout, Ca, Cs, ws_));
-  } else {
-    std::vector<WgradArgs> lw;
-    wgrad_launches(g, lw);
-    for (auto& a : lw) {
-      a.nsrc = E.fill_srcs(L, a.src);
-      a.dy = dy; a.dyC = dyC;
-      a.dW = E.grads + P->params[L.w].off;
-      a.stamp = nullptr;
-    }
-    if (L.transposed && lw.size() == 4 && wgrad_convt16_eligible(lw[0], P->dtype)) {   // ConvTranspose2d: the four parities in one launch
-      ProfScope ps(2, 2.0 * layer_macs(L), ws_, L.name);
-      HIPCHK(launch_wgrad_convt16(P->dtype, lw[0], ws_));
-      lw.clear();
-    }
-    const double nl = (double)lw.size();
-    for (auto& a : lw) {
-      ProfScope ps(2, 2.0 * layer_macs(L) / nl, ws_, L.name);
-      HIPCHK(launch_wgrad(P->dtype, a, ws_));
-    }
-  }
-  // data gradient
-  bool any = false;
-  for (auto& s : L.srcs) any = any || P->tensors[s.v.t].need_grad;
-  if (!any) return OCTSEG_OK;
-  if (L.tie & 2) {
-    // tied: the low-resolution source's gradient from the four parity planes of dy (2x2 taps each, all of them cover the whole map: the first
-    // stores unless somebody wrote before, the others add); the skip sources' from a 3x3 data gradient over their own channels
-    const int ti0 = L.srcs[0].v.t;
-    const TensorInfo& t0 = P->tensors[ti0];
-    const double macs = layer_macs(L);
-    std::vector<ConvArgs> lu;
-    const bool planes = tie_dgrad_planes() && !L.tie_du_masked;
-    if (L.tie_du_masked) { lu.resize(1); tied_dgrad_masked(tie_geom_up(L), lu[0]); }
-    else if (planes) tied_dgrad_launches(tie_geom_up(L), lu);
-    else dgrad_launches(tie_geom_up(L), lu);   // (one launch: 16 taps at stride 2 over dy)
-    const int acc0 = E.claim(ti0);
-    for (int k = 0; k < (int)lu.size(); ++k) {
-      ConvArgs& a = lu[k];
-      const int py = k >> 1, px = k & 1;
-      if (L.tie_du_masked) {
-        for (int p = 0; p < 4; ++p) {   // plane p of dy as a tensor of its own: first pixel (p >> 1, p & 1), doubled pixel and row strides
-          SrcDesc& s = a.src[p];
-          s.ptr = (const char*)dy + ((size_t)(p >> 1) * L.OW + (p & 1)) * dyC * esz;
-          s.scale = nullptr; s.shift = nullptr; s.C = 2 * dyC; s.c0 = p * L.Cout; s.H = L.OH / 2; s.W = L.OW; s.up = 0; s.relu = 0;
+    return OCTSEG_OK;
+  };
+  auto dgrad_part = [&]() -> int {
+    // data gradient
+    bool any = false;
+    for (auto& s : L.srcs) any = any || P->tensors[s.v.t].need_grad;
+    if (!any) return OCTSEG_OK;
+    if (L.tie & 2) {
+      // tied: the low-resolution source's gradient from the four parity planes of dy (2x2 taps each, all of them cover the whole map: the first
+      // stores unless somebody wrote before, the others add); the skip sources' from a 3x3 data gradient over their own channels
+      const int ti0 = L.srcs[0].v.t;
+      const TensorInfo& t0 = P->tensors[ti0];
+      const double macs = layer_macs(L);
+      std::vector<ConvArgs> lu;
+      const bool planes = tie_dgrad_planes() && !L.tie_du_masked;
+      if (L.tie_du_masked) { lu.resize(1); tied_dgrad_masked(tie_geom_up(L), lu[0]); }
+      else if (planes) tied_dgrad_launches(tie_geom_up(L), lu);
+      else dgrad_launches(tie_geom_up(L), lu);   // (one launch: 16 taps at stride 2 over dy)
+      const int acc0 = E.claim(ti0);
+      for (int k = 0; k < (int)lu.size(); ++k) {
+        ConvArgs& a = lu[k];
+        const int py = k >> 1, px = k & 1;
+        if (L.tie_du_masked) {
+          for (int p = 0; p < 4; ++p) {   // plane p of dy as a tensor of its own: first pixel (p >> 1, p & 1), doubled pixel and row strides
+            SrcDesc& s = a.src[p];
+            s.ptr = (const char*)dy + ((size_t)(p >> 1) * L.OW + (p & 1)) * dyC * esz;
+            s.scale = nullptr; s.shift = nullptr; s.C = 2 * dyC; s.c0 = p * L.Cout; s.H = L.OH / 2; s.W = L.OW; s.up = 0; s.relu = 0;
+          }
+        } else {
+          SrcDesc s;
+          s.ptr = (const char*)dy + (planes ? ((size_t)py * L.OW + px) * dyC * esz : 0);
+          s.scale = nullptr; s.shift = nullptr; s.C = planes ? 2 * dyC : dyC; s.c0 = 0; s.H = planes ? L.OH / 2 : L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
+          a.src[0] = s; a.nsrc = 1;
+          a.Cin = L.Cout;
         }
-      } else {
+        a.W = E.ws + L.tie_du_off;
+        DstDesc d;
+        d.ptr = E.grad(ti0); d.C = t0.C; d.c0 = 0; d.cn = L.tie_Ca; d.H = t0.H; d.W = t0.W; d.accum = k == 0 ? acc0 : 1; d.pool = 0;
+        a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
+        ProfScope ps(1, 2.0 * macs * L.tie_Ca / L.Cin / (double)lu.size(), E.st, L.name);
+        HIPCHK(launch_conv(P->dtype, a, E.st));
+      }
+      if (L.tie_Cs > 0) {
+        std::vector<ConvArgs> ls;
+        dgrad_launches(tie_geom_skip(L), ls);
+        ConvArgs& a = ls[0];
         SrcDesc s;
-        s.ptr = (const char*)dy + (planes ? ((size_t)py * L.OW + px) * dyC * esz : 0);
-        s.scale = nullptr; s.shift = nullptr; s.C = planes ? 2 * dyC : dyC; s.c0 = 0; s.H = planes ? L.OH / 2 : L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
+        s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
         a.src[0] = s; a.nsrc = 1;
         a.Cin = L.Cout;
+        a.W = E.ws + L.tie_ds_off;
+        int nd = 0, c0 = 0;
+        for (size_t i = 1; i < L.srcs.size(); ++i) {
+          const int ti = L.srcs[i].v.t;
+          const TensorInfo& t = P->tensors[ti];
+          DstDesc d;
+          d.ptr = E.grad(ti); d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = E.claim(ti); d.pool = 0;
+          a.dst[nd++] = d;
+          c0 += t.C;
+        }
+        a.ndst = nd; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
+        ProfScope ps(1, 2.0 * macs * L.tie_Cs / L.Cin, E.st, L.name);
+        HIPCHK(launch_conv(P->dtype, a, E.st));
       }
-      a.W = E.ws + L.tie_du_off;
-      DstDesc d;
-      d.ptr = E.grad(ti0); d.C = t0.C; d.c0 = 0; d.cn = L.tie_Ca; d.H = t0.H; d.W = t0.W; d.accum = k == 0 ? acc0 : 1; d.pool = 0;
-      a.dst[0] = d; a.ndst = 1; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
-      ProfScope ps(1, 2.0 * macs * L.tie_Ca / L.Cin / (double)lu.size(), E.st, L.name);
-      HIPCHK(launch_conv(P->dtype, a, E.st));
+      return OCTSEG_OK;
     }
-    if (L.tie_Cs > 0) {
-      std::vector<ConvArgs> ls;
-      dgrad_launches(tie_geom_skip(L), ls);
-      ConvArgs& a = ls[0];
+    std::vector<ConvArgs> ld;
+    dgrad_launches(g, ld);
+    // destinations: the forward sources' gradient buffers; upsampled sources go through a temp.  A destination
+    // that nobody has written yet in this backward is stored to (no memset + read-modify-write), unless this
+    // conv does not cover it completely (1x1 stride 2: only one pixel parity) -- then it is zeroed first.
+    bool full_cover = true;
+    for (auto& a : ld) if (a.ntaps == 0) full_cover = false;
+    DstDesc dst[MAX_SRC];
+    int nd = 0, c0 = 0;
+    int up_src = -1;
+    for (size_t i = 0; i < L.srcs.size(); ++i) {
+      const int ti = L.srcs[i].v.t;
+      const TensorInfo& t = P->tensors[ti];
+      const int scn = L.srcs[i].cn ? L.srcs[i].cn : t.C;      // channels of this source inside the layer's input (a slice for grouped convs)
+      const size_t soff = (size_t)L.srcs[i].c0 * esz;
+      DstDesc d;
+      d.C = t.C; d.c0 = c0; d.cn = scn; d.H = L.IH; d.W = L.IW; d.accum = 0; d.pool = 0;
+      static const bool no_fuse_pool = getenv("OCTSEG_NO_FUSED_POOL") != nullptr;
+      if (L.srcs[i].up && t.need_grad && !no_fuse_pool && ld.size() == 1 && ld[0].ostride == 1 && (L.IH % 2) == 0 && (L.IW % 2) == 0) {
+        // gradient of the nearest-x2 upsample: the dgrad epilogue sums the 2x2 quads straight into the source's gradient
+        d.ptr = E.grad(ti); d.H = t.H; d.W = t.W; d.pool = 1;
+        d.accum = E.claim(ti);
+      } else if (L.srcs[i].up) {
+        d.ptr = E.ws + P->tmp_off;     // fully covered by this dgrad, pooled into the source afterwards
+        up_src = (int)i;
+      } else if (!t.need_grad) {
+        d.ptr = E.ws + P->tmp_off; d.accum = 0;   // never happens for multi-source convs; keeps the descriptor valid
+      } else if (L.srcs[i].cn) {
+        // one group of a grouped conv: it owns a channel slice of the source's gradient.  The first group to arrive zeroes the whole
+        // tensor, every group then accumulates into its slice (first-writer stores are per tensor, not per slice)
+        if (!E.ginit[ti]) { HIPCHK(hipMemsetAsync(E.grad(ti), 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st)); E.ginit[ti] = 1; }
+        d.ptr = (char*)E.grad(ti) + soff;
+        d.accum = 1;
+      } else {
+        d.ptr = E.grad(ti);
+        d.accum = E.claim(ti);
+        if (!d.accum && !full_cover) {
+          HIPCHK(hipMemsetAsync(d.ptr, 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st));
+          d.accum = 1;
+        }
+      }
+      dst[nd++] = d;
+      c0 += scn;
+    }
+    for (auto& a : ld) {
       SrcDesc s;
       s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
       a.src[0] = s; a.nsrc = 1;
-      a.Cin = L.Cout;
-      a.W = E.ws + L.tie_ds_off;
-      int nd = 0, c0 = 0;
-      for (size_t i = 1; i < L.srcs.size(); ++i) {
-        const int ti = L.srcs[i].v.t;
-        const TensorInfo& t = P->tensors[ti];
-        DstDesc d;
-        d.ptr = E.grad(ti); d.C = t.C; d.c0 = c0; d.cn = t.C; d.H = L.IH; d.W = L.IW; d.accum = E.claim(ti); d.pool = 0;
-        a.dst[nd++] = d;
-        c0 += t.C;
-      }
-      a.ndst = nd; a.out_mode = OUT_STORE; a.bias = nullptr; a.stat_slab = nullptr;
-      ProfScope ps(1, 2.0 * macs * L.tie_Cs / L.Cin, E.st, L.name);
+      a.Cin = L.sliced ? L.Cout : dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero (a group: its own channels, dyC is the stride)
+      a.W = E.ws + L.wimg_dgrad_off;
+      if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 1; }
+      for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
+      a.ndst = nd;
+      a.out_mode = OUT_STORE;   // per-destination accumulate flags decide
+      a.bias = nullptr; a.stat_slab = nullptr;
+      ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st, L.name);
       HIPCHK(launch_conv(P->dtype, a, E.st));
     }
-    return OCTSEG_OK;
-  }
-  std::vector<ConvArgs> ld;
-  dgrad_launches(g, ld);
-  // destinations: the forward sources' gradient buffers; upsampled sources go through a temp.  A destination
-  // that nobody has written yet in this backward is stored to (no memset + read-modify-write), unless this
-  // conv does not cover it completely (1x1 stride 2: only one pixel parity) -- then it is zeroed first.
-  bool full_cover = true;
-  for (auto& a : ld) if (a.ntaps == 0) full_cover = false;
-  DstDesc dst[MAX_SRC];
-  int nd = 0, c0 = 0;
-  int up_src = -1;
-  for (size_t i = 0; i < L.srcs.size(); ++i) {
-    const int ti = L.srcs[i].v.t;
-    const TensorInfo& t = P->tensors[ti];
-    const int scn = L.srcs[i].cn ? L.srcs[i].cn : t.C;      // channels of this source inside the layer's input (a slice for grouped convs)
-    const size_t soff = (size_t)L.srcs[i].c0 * esz;
-    DstDesc d;
-    d.C = t.C; d.c0 = c0; d.cn = scn; d.H = L.IH; d.W = L.IW; d.accum = 0; d.pool = 0;
-    static const bool no_fuse_pool = getenv("OCTSEG_NO_FUSED_POOL") != nullptr;
-    if (L.srcs[i].up && t.need_grad && !no_fuse_pool && ld.size() == 1 && ld[0].ostride == 1 && (L.IH % 2) == 0 && (L.IW % 2) == 0) {
-      // gradient of the nearest-x2 upsample: the dgrad epilogue sums the 2x2 quads straight into the source's gradient
-      d.ptr = E.grad(ti); d.H = t.H; d.W = t.W; d.pool = 1;
-      d.accum = E.claim(ti);
-    } else if (L.srcs[i].up) {
-      d.ptr = E.ws + P->tmp_off;     // fully covered by this dgrad, pooled into the source afterwards
-      up_src = (int)i;
-    } else if (!t.need_grad) {
-      d.ptr = E.ws + P->tmp_off; d.accum = 0;   // never happens for multi-source convs; keeps the descriptor valid
-    } else if (L.srcs[i].cn) {
-      // one group of a grouped conv: it owns a channel slice of the source's gradient.  The first group to arrive zeroes the whole
-      // tensor, every group then accumulates into its slice (first-writer stores are per tensor, not per slice)
-      if (!E.ginit[ti]) { HIPCHK(hipMemsetAsync(E.grad(ti), 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st)); E.ginit[ti] = 1; }
-      d.ptr = (char*)E.grad(ti) + soff;
-      d.accum = 1;
-    } else {
-      d.ptr = E.grad(ti);
-      d.accum = E.claim(ti);
-      if (!d.accum && !full_cover) {
-        HIPCHK(hipMemsetAsync(d.ptr, 0, (size_t)t.N * t.H * t.W * t.C * esz, E.st));
-        d.accum = 1;
-      }
+    if (up_src >= 0) {
+      const TensorInfo& t = P->tensors[L.srcs[up_src].v.t];
+      const int ti = L.srcs[up_src].v.t;
+      const int acc = E.claim(ti);
+      HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(ti), E.ws + P->tmp_off, t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
     }
-    dst[nd++] = d;
-    c0 += scn;
-  }
-  for (auto& a : ld) {
-    SrcDesc s;
-    s.ptr = dy; s.scale = nullptr; s.shift = nullptr; s.C = dyC; s.c0 = 0; s.H = L.OH; s.W = L.OW; s.up = 0; s.relu = 0;
-    a.src[0] = s; a.nsrc = 1;
-    a.Cin = L.sliced ? L.Cout : dyC;  // contraction runs over the (padded) output channels; the pad columns of the image are zero (a group: its own channels, dyC is the stride)
-    a.W = E.ws + L.wimg_dgrad_off;
-    if (!L.stem && !L.transposed) { a.Wmaster = E.params + P->params[L.w].off; a.wO = L.Cout; a.wI = L.Cin; a.wtrans = 1; }
-    for (int i = 0; i < nd; ++i) a.dst[i] = dst[i];
-    a.ndst = nd;
-    a.out_mode = OUT_STORE;   // per-destination accumulate flags decide
-    a.bias = nullptr; a.stat_slab = nullptr;
-    ProfScope ps(1, 2.0 * layer_macs(L) / (double)ld.size(), E.st, L.name);
-    HIPCHK(launch_conv(P->dtype, a, E.st));
-  }
-  if (up_src >= 0) {
-    const TensorInfo& t = P->tensors[L.srcs[up_src].v.t];
-    const int ti = L.srcs[up_src].v.t;
-    const int acc = E.claim(ti);
-    HIPCHK(launch_pool2x2_accum(P->dtype, E.grad(ti), E.ws + P->tmp_off, t.N, t.H, t.W, t.C, acc ? 0 : 1, E.st));
-  }
+    return OCTSEG_OK;
+  };
+  if (wgrad_first) { const int rc = wgrad_part(); if (rc) return rc; }
+  { const int rc = dgrad_part(); if (rc) return rc; }
+  if (!wgrad_first) { const int rc = wgrad_part(); if (rc) return rc; }
   return OCTSEG_OK;
 }
 
