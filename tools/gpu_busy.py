@@ -4,6 +4,7 @@ import sqlite3, sys
 db = sys.argv[1]
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+MFMA = ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad_mfma', 'wgrad1x1', 'wgrad_convt16', 'thin_conv', 'thin_wgrad')
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 opt = [r for r in rows if 'optim_kernel' in r[0]]
@@ -18,7 +19,7 @@ def union(iv):
         else: ce = max(ce, e)
     return tot + ce - cs
 busy = union([(r[1], r[2]) for r in win])
-mf = [(r[1], r[2]) for r in win if any(k in r[0] for k in ('conv_mfma', 'conv3x3p', 'gemm1x1', 'wgrad_mfma', 'thin_conv', 'thin_wgrad'))]
+mf = [(r[1], r[2]) for r in win if any(k in r[0] for k in MFMA)]
 gaps = []
 import collections, re
 pair = collections.Counter(); pairn = collections.Counter()
@@ -40,3 +41,23 @@ durs = collections.Counter(); cnt = collections.Counter()
 for r in win: durs[short(r[0])] += r[2] - r[1]; cnt[short(r[0])] += 1
 print('kernel time per step (overlapped durations):')
 for k, v in durs.most_common(16): print(f'  {k:28s} {v / 1e6 / nlast:7.3f} ms {cnt[k] // nlast:5d} launches')
+
+# exposed time of the other kernels: the part of each interval during which no MFMA kernel runs (what overlap does NOT hide)
+mu = []
+for s_, e_ in sorted(mf):
+    if mu and s_ <= mu[-1][1]: mu[-1][1] = max(mu[-1][1], e_)
+    else: mu.append([s_, e_])
+import bisect
+starts = [m[0] for m in mu]
+def exposed(s_, e_):
+    cov = 0; i = max(0, bisect.bisect_right(starts, s_) - 1)
+    while i < len(mu) and mu[i][0] < e_:
+        cov += max(0, min(e_, mu[i][1]) - max(s_, mu[i][0])); i += 1
+    return (e_ - s_) - cov
+ex = collections.Counter(); tot = collections.Counter()
+for r in win:
+    if any(k in r[0] for k in MFMA): continue
+    ex[short(r[0])] += exposed(r[1], r[2]); tot[short(r[0])] += r[2] - r[1]
+print('non-MFMA kernels: duration and the part of it with NO MFMA kernel running beside (ms per step):')
+for k, v in ex.most_common(12): print(f'  {k:28s} {tot[k] / 1e6 / nlast:7.3f} ms, exposed {v / 1e6 / nlast:7.3f}')
+print(f'  total exposed {sum(ex.values()) / 1e6 / nlast:.3f} ms per step')
