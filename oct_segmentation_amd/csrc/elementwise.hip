@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* params, char
       if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
     }
     const PackJob jb = tab[lo];
+    if (fold && jb.src_I != 0) continue;   // images of the tied decomposition: training only, never read by an eval forward
     const float* w = params + jb.src_off;
     const int VPR = jb.RB / 16, KC = jb.RB / (int)sizeof(T), swz_div = 256 / jb.RB;
     const int rows = jb.transpose ? jb.I : jb.O, K = jb.transpose ? jb.O : jb.I, sI = jb.src_I ? jb.src_I : jb.I;
