@@ -261,17 +261,19 @@ static int tie_mask() {   // (read when a plan is built, so that one process can
 }
 
 // ================================================================ graph builder
-// The side stream carries work that is off the critical chain (weight gradients, the second forward lane).  It is created with the LOWEST stream
-// priority: the chain's kernels win the dispatch whenever compute units free up, the weight gradients fill what is left (round 4, ABAB on one
-// box, eager steps: 67.75-68.0 ms per step against 68.2-68.3 at the default priority, 69.1 at the highest; under graph replay round 3 saw no
-// difference).  OCTSEG_SIDE_PRIORITY=normal|high restores / inverts it (A/B switch).
-static hipError_t create_side_stream(hipStream_t* st) {
+// Side streams carry work that is off the critical chain: the second forward lane (default priority -- at low priority the fp16 ensemble's
+// B = 1 replay, whose lanes ARE its critical path, fell from 148 to 121 frames/s) and the backward's weight gradients.  The latter's stream is
+// created with the LOWEST priority: the chain's kernels win the dispatch whenever compute units free up, the weight gradients fill what is
+// left (round 4, ABAB on one box, eager steps: 67.75-68.0 ms per step against 68.2-68.3 at the default priority, 69.1 at the highest; under
+// graph replay round 3 saw no difference).  OCTSEG_SIDE_PRIORITY=normal|high|low sets both (A/B switch).
+static hipError_t create_side_stream(hipStream_t* st, bool backward = false) {
   static const char* pr = getenv("OCTSEG_SIDE_PRIORITY");
-  if (pr == nullptr || pr[0] == 'l' || pr[0] == 'h') {
+  const char mode = pr != nullptr ? pr[0] : (backward ? 'l' : 'n');
+  if (mode == 'l' || mode == 'h') {
     int least = 0, greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return e;
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, (pr == nullptr || pr[0] == 'l') ? least : greatest);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, mode == 'l' ? least : greatest);
   }
   // (a side stream confined to a share of the compute units -- hipExtStreamCreateWithCUMask, 6 / 4 / 7 of every 8 CUs -- so that the caller's
   //  stream always finds free CUs for its sweeps: 75.2 -> 91.7 ms per step whatever the share; measured once, not kept)
@@ -1541,12 +1543,17 @@ static int run_forward(Exec& E, const float* image, float* logits, int normalize
   const bool lanes = P->has_lanes && !no_lanes && !serial_mode();
   hipStream_t lst[2] = {E.st, E.st};
   if (lanes) {
-    if (!P->side) {
-      HIPCHK(create_side_stream(&P->side));
+    // training forwards share the backward's lowest-priority stream (the second lane yields to the encoder chain: 69.1 / 68.6 against 69.7 /
+    // 69.0 ms per step, ABAB); eval forwards -- the ensemble's B = 1 replay, whose lanes are its critical path -- and captured steps keep the
+    // default priority
+    const bool low = E.train && !P->tgraph_enabled;
+    hipStream_t* lsp = low ? &P->side_bwd : &P->side;
+    if (!*lsp) HIPCHK(create_side_stream(lsp, low));
+    if (!P->ev_fork) {
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
     }
-    lst[1] = P->side;
+    lst[1] = *lsp;
   }
   std::vector<int> tseq(P->tensors.size(), 0), bseq(P->bns.size(), 0);   // producer: lane * 2^24 + sequence number on it
   int enq[2] = {1, 0}, seen[2] = {0, 0};   // ops enqueued per lane (main starts at 1: everything in front of the loop);
@@ -2262,15 +2269,18 @@ static int run_backward(Exec& E, const float* logits, const float* target, float
   E.ginit.assign(P->tensors.size(), 0);
   static const bool no_side = getenv("OCTSEG_NO_SIDE_STREAM") != nullptr;   // A/B switch
   if (!no_side && !serial_mode()) {
-    if (!P->side) {
-      HIPCHK(create_side_stream(&P->side));
+    // (a step that is being captured / replayed as one hipGraph keeps the default priority: replaying a graph whose side branch was captured
+    //  from a lowest-priority stream took 34.9 instead of 20.7 ms per step at 2 frames, profiles/r4_graph_ab.txt)
+    hipStream_t* wsp = P->tgraph_enabled ? &P->side : &P->side_bwd;
+    if (!*wsp) HIPCHK(create_side_stream(wsp, !P->tgraph_enabled));
+    if (!P->ev_fork) {
       HIPCHK(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
     }
-    E.wst = P->side;
+    E.wst = *wsp;
     // the side stream must see the zeroed parameter-gradient arena
     HIPCHK(hipEventRecord(P->ev_fork, E.st));
-    HIPCHK(hipStreamWaitEvent(P->side, P->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(E.wst, P->ev_fork, 0));
   }
   // dL/dlogits (NHWC, padded channels)
   DiceArgs da;
@@ -2635,6 +2645,7 @@ int octseg_plan_create(const octseg_net_desc* d, octseg_plan** out) {
 int octseg_plan_destroy(octseg_plan* p) {
   if (p) {
     if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->side_bwd) (void)hipStreamDestroy(p->side_bwd);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->ev_slice) (void)hipEventDestroy(p->ev_slice);

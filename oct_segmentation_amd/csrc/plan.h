@@ -192,7 +192,8 @@ struct octseg_plan {
   std::vector<unsigned> bn_prefix;
   unsigned bn_total = 0;
   size_t bn_tab_off = 0, bn_prefix_off = 0;
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;        // second forward lane (default priority)
+  hipStream_t side_bwd = nullptr;    // weight gradients of the backward (lowest priority: they yield to the chain's kernels)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_slice = nullptr;
   // eval forward as a hipGraph (octseg_plan_set_graph): captured on the second call with an unchanged argument set,
   // replayed while that set stays the same (a B=1 predict is ~400 launches of a few microseconds each)
