@@ -128,6 +128,20 @@ def test_tied_all_passes(cuda, arch, enc, probe):
     assert torch.isfinite(f1).all()
 
 
+@pytest.mark.parametrize('tied', ['d', 'w'])
+def test_tied_gradients_on_ragged_maps(cuda, tied):
+    """96 x 96 frames, three of them: decoder maps of 6, 12, 24, 48 pixels a side (3 x 3 low-resolution sources, tiles of 8 x 16 and 16 x 16 pixels
+    filled to a fraction, an odd batch) through the fused ConvTranspose2d weight gradient and the masked parity-plane data gradient."""
+    a = _step(cuda, 'unetplusplus', 'resnet18', '', S=96, B=3)
+    b = _step(cuda, 'unetplusplus', 'resnet18', tied, S=96, B=3)
+    _check_macs(a, b, tied)
+    assert b['loss'] == a['loss'] and torch.equal(b['logits'], a['logits'])
+    for k, g0 in a['grads'].items():
+        g1 = b['grads'][k]
+        if float(g0.norm()) > 0 and g0.numel() >= 16:
+            assert _cos(g0, g1) >= (0.999999 if tied == 'w' else 0.9995), f'{k}: cosine {_cos(g0, g1)} with OCTSEG_TIED={tied}'
+
+
 def test_tied_default_is_the_two_gradients(cuda):
     from oct_segmentation_amd.engine import SegNet
     old = os.environ.pop('OCTSEG_TIED', None)
