@@ -896,26 +896,33 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
         uint4 av[PPT];
         bool aok[PPT];
         char* wr[PPT];
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) {
-          av[u] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[u]);
-          wr[u] = wrow;
-          const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
-          if (adv) {
-            hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
-            hy += dq; hx += dr;
-            if (hx >= RW) { hx -= RW; hy += 1; }
-          }
-        }
         // slab of the next iteration: the next tap of this chunk's list, or the first of the next chunk's
         const bool same = k + 1 < tps;
         const int tn = same ? (lst >> (4 * (k + 1))) & 15 : lst_n & 15;
-        dmaB(__builtin_amdgcn_readlane(v_tapw, tn) * nchunks + (same ? chunk : cnext), (it + 1) & 1);
         const int toff = __builtin_amdgcn_readlane(v_toff, t);
-        mma_tap(awin, ldsB + (it & 1) * BBYTES, toff);
-        __builtin_amdgcn_sched_barrier(0);
+        // the prefetches behind the first k-step's MFMAs, the LDS stores of the window passes behind the third's (mma_tap_f): the MFMAs just
+        // issued execute while the wave runs them
+        mma_tap_f(awin, ldsB + (it & 1) * BBYTES, toff,
+          [&]() {
+            dmaB(__builtin_amdgcn_readlane(v_tapw, tn) * nchunks + (same ? chunk : cnext), (it + 1) & 1);
 #pragma unroll
-        for (int u = 0; u < PPT; ++u) nxt.write_at(wr[u], av[u], aok[u]);
+            for (int u = 0; u < PPT; ++u) {
+              av[u] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[u]);
+              wr[u] = wrow;
+              const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+              if (adv) {
+                hp += Stager::PSTEP; wrow += Stager::PSTEP * PITCH;
+                hy += dq; hx += dr;
+                if (hx >= RW) { hx -= RW; hy += 1; }
+              }
+            }
+          },
+          [&]() {},
+          [&]() {
+#pragma unroll
+            for (int u = 0; u < PPT; ++u) nxt.write_at(wr[u], av[u], aok[u]);
+          });
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
