@@ -1313,6 +1313,14 @@ static Choice choose(const ConvArgs& a, int esz) {
   }
   int NT, WN;
   if (a.Cout > 64) { NT = 2; WN = 2; } else if (a.Cout > 32) { NT = 1; WN = 2; } else { NT = 1; WN = 1; }
+  {
+    // K-thin layers (one K chunk: the data gradients of the 64-channel decoder layers) whose 128-channel tiling leaves a quarter or more of
+    // its last N tile empty take 64-channel N tiles: 192 <- 64 @352^2 (the skip half of x_1_3.conv1's tied data gradient) 1.090 -> 0.925 ms.
+    // With several K chunks the lost A reuse costs more than the empty half tile (192 <- 256 @176^2: 0.677 -> 0.727 ms).
+    static const bool off = getenv("OCTSEG_NO_BN64_THIN") != nullptr;   // A/B switch
+    const int t128 = (a.Cout + 127) / 128;
+    if (!off && a.Cout > 64 && a.ntaps == 9 && a.Cin <= 128 / esz && a.Cout % 64 == 0 && (t128 * 128 - a.Cout) * 4 >= t128 * 128) { NT = 1; WN = 2; }
+  }
   // Small grids (small per-GPU batches -- strong scaling -- and the deepest stages): a multi-tap layer whose 16x16-pixel x 128-channel
   // tiles number fewer than half the CUs runs at the speed of ONE workgroup's loop (U-Net++/resnet101 at 2 frames per GPU: x_0_0.conv1,
   // 3072 -> 256 @44^2, is 36 workgroups of 27648-deep contractions: 166 TFLOP/s).  A 64-channel N tile and the 8x16-pixel M tile
