@@ -72,6 +72,38 @@ def test_graph_matches_oracle_tree_and_survey_macs(arch, enc, classes, S, gmac):
         lib.octseg_plan_destroy(p)
 
 
+def test_executed_macs_of_the_tied_decoder_layers(monkeypatch):
+    """octseg_plan_exec_macs: the reference graph's count never moves; the tied passes of the nearest-x2 + 3x3 decoder layers
+    execute 4/9 of it over the upsampled source's channels.  U-Net++/resnet101 at 704^2: 182.7 of 471.07 GMAC lie on upsampled channels
+    (DESIGN.md section 7.7), so a tied pass executes 471.07 - 182.7 * 5 / 9 less what the narrow layers (below 64 channels) keep."""
+    lib = L.lib()
+
+    def macs(env, dt=L.BF16, arch='unetplusplus', enc='resnet101'):
+        if env is None:
+            monkeypatch.delenv('OCTSEG_TIED', raising=False)
+        else:
+            monkeypatch.setenv('OCTSEG_TIED', env)
+        rc, p = _plan(arch, enc, 1, 1, 704, 704, dt)
+        assert rc == 0, lib.octseg_last_error()
+        try:
+            out = (C.c_double * 3)()
+            assert lib.octseg_plan_exec_macs(p, out) == 0
+            return lib.octseg_plan_fwd_macs(p), tuple(out)
+        finally:
+            lib.octseg_plan_destroy(p)
+    alg, ex = macs(None)                                   # default: the two gradients
+    assert alg / 1e9 == pytest.approx(471.07, abs=0.02)
+    assert ex[0] == alg and ex[1] == ex[2] and 0.77 * alg < ex[1] < 0.80 * alg     # 370.86 GMAC: -21.3 % of every conv MAC of the pass
+    assert (alg - ex[1]) / 1e9 == pytest.approx(182.7 * 5 / 9, rel=0.02)
+    assert macs('0') == (alg, (alg, alg, alg))
+    assert macs('f')[1] == (ex[1], alg, alg)
+    assert macs('fdw')[1] == (ex[1], ex[1], ex[1])
+    assert macs(None, L.F32)[1] == (alg, alg, alg)          # fp32 plans keep the reference's summation
+    a2, e2 = macs(None, arch='linknet', enc='resnet50')     # no nearest-x2 + 3x3 layer in the graph
+    assert e2 == (a2, a2, a2)
+    assert lib.octseg_plan_exec_macs(None, (C.c_double * 3)()) != 0
+
+
 def test_plan_argument_validation():
     lib = L.lib()
     rc, _ = _plan('unet', 'resnet18', 1, 1, 100, 100)
