@@ -73,8 +73,9 @@ struct TilePos { int n, y0, x0, co0, w_mt, nt_idx; };
 //   M-major (1): the N tiles of one M tile are neighbours -- the activation window is fetched once instead of once
 //                per N tile, and the (small) weight set is L2-resident on every XCD (ResNet bottleneck shapes).
 // Speed only -- any placement is correct.
-template <int TH, int BN>
+template <int TH_, int BN, bool T11 = false>
 static __device__ __forceinline__ TilePos map_tile(const ConvArgs& a) {
+  constexpr int TH = T11 ? 11 : TH_, TW = T11 ? 11 : octseg::TW;   // (T11: 11 x 11 pixel tiles, LOOP_T11)
   const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
   const int n_mt = gridDim.x, n_nt = gridDim.y;
   const int lid = blockIdx.x + blockIdx.y * n_mt;
@@ -109,7 +110,7 @@ template <typename T> __host__ __device__ constexpr bool conv_m16(int mt) { retu
 
 // Epilogue shared by the conv kernels: bias, BN partials, LDS transpose, 16-byte stores / accumulates.
 // All waves must be past their last LDS read of the main loop (barrier) when this is entered.
-template <typename T, int NT, int WN, int WM, bool GROUPED, int MT>
+template <typename T, int NT, int WN, int WM, bool GROUPED, int MT, bool T11 = false>
 static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* smem, f32x16_t (&acc)[conv_m16<T>(MT) ? 1 : MT][conv_m16<T>(MT) ? 1 : NT],
                                                      f32x4_t (&acc16)[conv_m16<T>(MT) ? 2 * MT : 1][conv_m16<T>(MT) ? 2 * NT : 1], const TilePos& tp) {
   // 2-byte types accumulate in 16 x 16 blocks (v_mfma_f32_16x16x32: block row mb = tile row wm * 2 * MT + mb, element j of lane (r16, g) =
@@ -138,7 +139,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     // Fast path (block-uniform): tile fully inside the output, one destination.  Everything below is the same
     // arithmetic in the same order as the general path, minus the per-element bounds checks, the destination
     // search and the per-vector 64-bit address math (the general path is ~4000 instructions per thread).
-    if (!head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
+    if (!T11 && !head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
       constexpr int ES = (int)sizeof(T);
       // accumulator element i of lane (r, h) is A row rr = (i & 3) + 8 * (i >> 2) + 4 * h; its pixel inside the wave's strip:
       //   plain row map:   row (i >> 3), column (i & 3) + 8 * ((i >> 2) & 1) + 4 * h
@@ -338,11 +339,14 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
       for (int mb = 0; mb < 2 * MT; ++mb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int ty = wm * 2 * MT + mb, tx = 4 * g16 + j;
+          int ty = wm * 2 * MT + mb, tx = 4 * g16 + j;
+          const int prow = ty * TW + tx;          // A row of this element = its row in the transposed tile
+          bool pv = true;
+          if constexpr (T11) { pv = prow < 121; ty = pv ? prow / 11 : 0; tx = pv ? prow - ty * 11 : 0; }   // 11 x 11 pixels on 128 rows
           const int gy = y0 + ty, gx = x0 + tx;
           float val = acc16[mb][nb][j] + bias;
           if (a.relu_out) val = clamp_lo(val, 0.f);
-          if (cok && gy < a.OH && gx < a.OW) {
+          if (cok && pv && gy < a.OH && gx < a.OW) {
             s1[nb] += val; s2[nb] += val * val;
             if (head) {
               const DstDesc& d = a.dst[0];
@@ -350,7 +354,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
               ((float*)d.ptr)[(((size_t)n * a.Cout + co) * d.H + oy) * d.W + ox] = val;
             }
           }
-          if (!head) *(unsigned short*)(otile + (ty * TW + tx) * OPITCH + cl * 2) = Tr<T>::bits16(val);
+          if (!head) *(unsigned short*)(otile + prow * OPITCH + cl * 2) = Tr<T>::bits16(val);
         }
     }
   } else
@@ -424,7 +428,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     // cooperative store: every thread moves whole 16-byte channel vectors of one pixel
     for (int v = tid; v < BM * OVPR; v += NTHREADS) {
       const int p = v / OVPR, cvv = v % OVPR;
-      const int ty = p >> 4, tx = p & 15;
+      int ty = p >> 4, tx = p & 15;
+      if constexpr (T11) { if (p >= 121) continue; ty = p / 11; tx = p - ty * 11; }
       const int gy = y0 + ty, gx = x0 + tx;
       const int co = co0 + cvv * VEC;
       if (gy >= a.OH || gx >= a.OW || co >= a.Cout) continue;
@@ -501,7 +506,11 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 //                               2 1x1 (one tap, four window passes per chunk)   3 run9r (3x3, slab ring)
 //                               4 run9s (3x3, ONE K chunk: slab ring only -- the K-thin data gradients of the decoder)
 //                               5 masked (per-source tap subsets, ConvArgs::taps_per_src: the rolled loop over each chunk's own taps, two window passes per tap)
-enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4, LOOP_MASKED = 5 };
+//                               6 the rolled loop on 11 x 11 pixel tiles (121 of the 128 rows of the 8 x 16 variant's M tile; single window
+//                                 buffer, two workgroups per CU): 3x3 layers on maps that are multiples of 11 but not of 16 -- every 88^2 / 44^2 /
+//                                 22^2 map of a 704^2 frame -- whose 16-pixel tiling ends in a nearly empty round (44^2 at 16 frames: 288 workgroups
+//                                 on 256 CUs; here 512 on 512 slots) or half-empty tiles (22^2: 47 % -> 94.5 %)
+enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4, LOOP_MASKED = 5, LOOP_T11 = 6 };
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 2) ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
@@ -530,15 +539,17 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
-  const TilePos tp = map_tile<TH, BN>(a);
+  constexpr bool T11 = LOOP == LOOP_T11;
+  const TilePos tp = map_tile<TH, BN, T11>(a);
   const int n = tp.n, y0 = tp.y0, x0 = tp.x0, nt_idx = tp.nt_idx;
 
   // window geometry
   const bool single = a.ntaps == 1;
   const int lstride = single ? 1 : a.istride;   // LDS lookup stride
   const int smul = single ? a.istride : 1;      // staging coordinate multiplier
-  const int RH = single ? TH : (TH - 1) * a.istride + a.span_y;
-  const int RW = single ? TW : (TW - 1) * a.istride + a.span_x;
+  constexpr int THe = T11 ? 11 : TH, TWe = T11 ? 11 : TW;
+  const int RH = single ? THe : (THe - 1) * a.istride + a.span_y;
+  const int RW = single ? TWe : (TWe - 1) * a.istride + a.span_x;
   const int npix = RH * RW;
   const int npass = (npix + Stager::PSTEP - 1) / Stager::PSTEP;
   const float inv_rw = 1.0f / (float)RW;
@@ -568,8 +579,14 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   const int r16 = lane & 15, g16 = lane >> 4;
   int abase16[2 * MT], bbase16[2 * NT], bswz16[2 * NT];
 #pragma unroll
-  for (int mb = 0; mb < 2 * MT; ++mb)   // block row mb = tile row wm * 2 MT + mb: 16 lanes read 16 consecutive pixels, conflict-free at pitch RB + 16
+  for (int mb = 0; mb < 2 * MT; ++mb) {   // block row mb = tile row wm * 2 MT + mb: 16 lanes read 16 consecutive pixels, conflict-free at pitch RB + 16
     abase16[mb] = (((wm * 2 * MT + mb) * lstride) * RW + r16 * lstride) * PITCH + g16 * 16;
+    if constexpr (T11) {   // A row p = 16 (wm 2 MT + mb) + r16 is pixel (p / 11, p % 11) of the 11 x 11 tile; rows 121 .. 127 re-read the last pixel
+      const int p = min((wm * 2 * MT + mb) * 16 + r16, 120);
+      const int pty = p / 11;
+      abase16[mb] = (pty * RW + (p - pty * 11)) * PITCH + g16 * 16;
+    }
+  }
 #pragma unroll
   for (int nb = 0; nb < 2 * NT; ++nb) {
     const int row = wn * NT * 32 + nb * 16 + r16;
@@ -1197,7 +1214,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
 #ifdef OCTSEG_STAMP
   STAMP(k2);
 #endif
-  conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED, MT>(a, smem, acc, acc16, tp);
+  conv_epilogue<T, NT, WN, WM, ROWMAP_GROUPED, MT, T11>(a, smem, acc, acc16, tp);
 #ifdef OCTSEG_STAMP
   STAMP(k3);
   if (a.stamp != nullptr && lane == 0) {
@@ -1232,7 +1249,7 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 hipError_t launch_loop(const ConvArgs& a, int mode, size_t lds, hipStream_t st) {
   constexpr int BN = NT * 32 * WN, TH = 2 * wave_mt(NT, RB) * WM;
-  const int mtiles = a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
+  const int mtiles = LOOP == LOOP_T11 ? a.N * (a.OH / 11) * (a.OW / 11) : a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
   dim3 grid(mtiles, (a.Cout + BN - 1) / BN);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1259,17 +1276,46 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
     case LOOP_MASKED:
       if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_MASKED>(a, mode, lds, st);
       else return hipErrorInvalidValue;
+    case LOOP_T11:
+      if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2 && WN == 2 && WM == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_T11>(a, mode, lds, st);
+      else return hipErrorInvalidValue;
     default: return launch_loop<T, NT, WN, WM, RB, LOOP_GENERIC>(a, mode, lds, st);
   }
 }
 
 // Tile choice: N tile from Cout, K chunk from Cin, M tile (16x16 or 8x16 pixels) from tile utilisation
 // and LDS fit (double-buffered window preferred).
-struct Choice { Variant v; int dbuf; size_t lds; int resident; int ring3; int ring1; };   // ring3: run9r, ring1: run9s (one chunk)
+struct Choice { Variant v; int dbuf; size_t lds; int resident; int ring3; int ring1; int tile11; };   // ring3: run9r, ring1: run9s (one chunk)
+
+// LOOP_T11's launches: 2-byte 3x3 stride-1 layers with > 64 output channels on maps that are multiples of 11 and not of 16, up to 88 pixels a
+// side, whose 16-pixel tiling is a small grid (<= 1024 workgroups: above that the persistent / ring loops win by their K loop).  `pool_ok` =
+// false: the geometry alone (a pooled destination needs even tiles -- such a launch keeps the 16-pixel tiling but must keep the same weight image)
+static bool tile11_geom(const ConvArgs& a, int esz) {
+  static const bool off = getenv("OCTSEG_NO_TILE11") != nullptr;   // A/B switch
+  if (off || esz != 2 || a.taps_per_src > 0) return false;
+  if (a.ntaps != 9 || a.span_x != 3 || a.span_y != 3 || a.istride != 1 || a.ostride != 1 || a.ooy != 0 || a.oox != 0) return false;
+  if (a.out_mode == OUT_HEAD_NCHW || a.IH != a.OH || a.IW != a.OW || a.OH % 11 != 0 || a.OW % 11 != 0 || a.OH > 88 || a.OW > 88) return false;
+  if (a.OH % 16 == 0 && a.OW % 16 == 0) return false;
+  if (a.Cout <= 64 || a.Cin < 64) return false;
+  const long long wg16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + 15) / 16) * ((a.Cout + 127) / 128);
+  return wg16 <= 1024;
+}
 
 static Choice choose(const ConvArgs& a, int esz) {
   Choice c;
-  c.ring3 = 0; c.ring1 = 0;
+  c.ring3 = 0; c.ring1 = 0; c.tile11 = 0;
+  const bool t11 = tile11_geom(a, esz);
+  if (t11) {
+    bool pool = false;
+    for (int i = 0; i < a.ndst; ++i) pool = pool || a.dst[i].pool != 0;
+    if (!pool) {   // 13 x 13 window = 6 passes of 32 pixels, two slab slots: 60 KB -> two workgroups per CU
+      c.v = Variant{2, 2, 2, 128}; c.dbuf = 0; c.resident = 0; c.tile11 = 1;
+      const size_t main_loop = (size_t)6 * 32 * 144 + 2 * (size_t)128 * 128;
+      const size_t epi = (size_t)128 * (128 * esz + 16) + (size_t)2 * 128 * 2 * sizeof(float);
+      c.lds = main_loop > epi ? main_loop : epi;
+      return c;
+    }
+  }
   if (a.taps_per_src > 0) {   // masked loop: the 128-channel N tile, 64-channel chunks, double-buffered window (conv_masked_eligible checked the rest)
     for (int wm = 4; wm >= 2; wm -= 2) {
       const Variant v{2, 2, wm, 128};
@@ -1299,7 +1345,7 @@ static Choice choose(const ConvArgs& a, int esz) {
     const bool p3 = !no_p3 && esz == 2 && a.ostride == 1 && a.OH % 16 == 0 && a.OW % 16 == 0 && a.IH == a.OH && a.IW == a.OW;
     const bool fits = !p3 && a.Cout == 256 && a.Cin >= 256 && (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + TW - 1) / TW) >= 1024;
     static const bool all = getenv("OCTSEG_N256_ALL") != nullptr;   // experiments: every >= 256-channel 3x3 layer
-    if (!off && (fits || all) && a.ntaps == 9 && a.istride == 1 && a.Cout > 128 && (n256 * 256 - a.Cout) * 10 <= a.Cout && a.Cin > kc) {
+    if (!off && !t11 && (fits || all) && a.ntaps == 9 && a.istride == 1 && a.Cout > 128 && (n256 * 256 - a.Cout) * 10 <= a.Cout && a.Cin > kc) {
       const Variant v{4, 2, 2, 64};   // 2 x 2 waves of (4 M sub-tiles x 4 N sub-tiles)
       int npass = 0;
       const size_t lds = variant_lds(a, v, esz, 1, &npass);
@@ -1421,7 +1467,7 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
     static const bool no_usrc = getenv("OCTSEG_NO_UNIFORM_SRC") != nullptr;   // A/B switch
     if (no_usrc) a.src_uniform = 0;
   }
-  const int loop = a.taps_per_src > 0 ? LOOP_MASKED
+  const int loop = c.tile11 ? LOOP_T11 : a.taps_per_src > 0 ? LOOP_MASKED
                    : c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
@@ -1458,6 +1504,7 @@ ConvPackInfo conv_pack_info(const ConvArgs& a, int dtype) {
 
 int conv_num_mtiles(const ConvArgs& a, int dtype) {
   const Choice c = choose(a, (int)dtype_size(dtype));
+  if (c.tile11) return a.N * (a.OH / 11) * (a.OW / 11);
   const int TH = 2 * wave_mt(c.v.NT, c.v.RB) * c.v.WM;
   return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
 }

@@ -190,7 +190,10 @@ def test_bf16_engine_vs_fp32_oracle_bottleneck_256(cuda, cfg):
     assert abs(d_eng - d_ref) <= max(1e-3, 1.5 * abs(d_ac - d_ref))
 
 
-@pytest.mark.parametrize('cfg', [('unet', 'resnet50', 1, 4, 128), ('linknet', 'resnet50', 2, 4, 128), ('fpn', 'resnet50', 1, 4, 128)],
+@pytest.mark.parametrize('cfg', [('unet', 'resnet50', 1, 4, 128), ('linknet', 'resnet50', 2, 4, 128), ('fpn', 'resnet50', 1, 4, 128),
+                                 # 352^2 frames: maps of 88, 44, 22 and 11 pixels -- multiples of 11 and not of 16: the 3x3 layers of the
+                                 # encoder's last three stages and of the deep decoder blocks run on 11 x 11 pixel tiles (conv_mfma.hip LOOP_T11)
+                                 ('unet', 'resnet50', 1, 2, 352)],
                          ids=lambda c: '-'.join(map(str, c)))
 def test_bf16_every_weight_gradient_direction(cuda, cfg):
     """Per-PARAMETER check of the bf16 engine against the fp32 oracle (kink-free nets): the cosine of every conv / ConvTranspose weight

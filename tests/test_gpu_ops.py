@@ -67,6 +67,13 @@ CASES = [
     # low-resolution map (12 x 20), 1.5 ci tiles x 2.5 co tiles; and 60 tiles walked by split-K workgroups (window / plane double buffers)
     (2, 12, 20, 96, 160, 4, 2, 1, True),
     (4, 40, 48, 128, 64, 4, 2, 1, True),
+    # 11 x 11 pixel tiles (conv_mfma.hip LOOP_T11, bf16): maps that are multiples of 11 and not of 16 -- the 88^2 / 44^2 / 22^2 maps of a 704^2 frame;
+    # forward and data gradient (> 64 channels on the output side of either), a half-filled second N tile, a non-square map, one tile per image
+    (2, 44, 44, 128, 256, 3, 1, 1, False),
+    (3, 22, 22, 192, 128, 3, 1, 1, False),
+    (1, 88, 88, 128, 128, 3, 1, 1, False),
+    (2, 33, 55, 128, 192, 3, 1, 1, False),
+    (2, 11, 11, 256, 128, 3, 1, 1, False),
 ]
 
 
