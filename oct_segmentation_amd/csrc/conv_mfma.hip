@@ -139,7 +139,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
     // Fast path (block-uniform): tile fully inside the output, one destination.  Everything below is the same
     // arithmetic in the same order as the general path, minus the per-element bounds checks, the destination
     // search and the per-vector 64-bit address math (the general path is ~4000 instructions per thread).
-    if (!T11 && !head && y0 + TH <= a.OH && x0 + TW <= a.OW) {
+    if (!head && (T11 || (y0 + TH <= a.OH && x0 + TW <= a.OW))) {   // (11 x 11 tiles divide their maps: always whole)
       constexpr int ES = (int)sizeof(T);
       // accumulator element i of lane (r, h) is A row rr = (i & 3) + 8 * (i >> 2) + 4 * h; its pixel inside the wave's strip:
       //   plain row map:   row (i >> 3), column (i & 3) + 8 * ((i >> 2) & 1) + 4 * h
@@ -166,7 +166,9 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
                 float val = acc16[mb][nb][j];
                 if constexpr (HAS_BIAS) val += bias;
                 if constexpr (HAS_RELU) val = clamp_lo(val, 0.f);
-                if constexpr (HAS_STAT) { s1[nb] += val; s2[nb] += val * val; }
+                if constexpr (HAS_STAT) {
+                  if (!T11 || (wm * 2 * MT + mb) * TW + 4 * g16 + j < 121) { s1[nb] += val; s2[nb] += val * val; }   // (rows 121 .. 127 of an 11 x 11 tile repeat its last pixel)
+                }
                 *(unsigned short*)(otile + ((wm * 2 * MT + mb) * TW + 4 * g16 + j) * OPITCH + cl * ES) = Tr<T>::bits16(val);
               }
           }
@@ -280,6 +282,28 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, char* sm
             }
           }
           *gq = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        }
+        return;
+      }
+      if constexpr (T11) {   // rows of 11 pixels: the sweeps of 16 pixels do not follow the image rows -- one address per vector
+        const char* lp = otile + p * OPITCH + cvv * 16;
+        const bool accum = a.out_mode == OUT_ACCUM || dacc;
+#pragma unroll
+        for (int k = 0; k < BM / PPI; ++k) {
+          const int pp = p + k * PPI;
+          if (pp >= 121) break;
+          const int ty = pp / 11, tx = pp - ty * 11;
+          uint4* gq = (uint4*)(dptr + ((((size_t)n * dH + (y0 + ty)) * dW + (x0 + tx)) * dC + (cov - dc0)) * ES);
+          uint4 val = *(const uint4*)(lp + k * PPI * OPITCH);
+          if (accum) {
+            const uint4 old = *gq;
+            unsigned nv[4] = {val.x, val.y, val.z, val.w};
+            const unsigned ov[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nv[i] = Tr<T>::pk(Tr<T>::lo(nv[i]) + Tr<T>::lo(ov[i]), Tr<T>::hi(nv[i]) + Tr<T>::hi(ov[i]));
+            val = make_uint4(nv[0], nv[1], nv[2], nv[3]);
+          }
+          *gq = val;
         }
         return;
       }
@@ -1298,7 +1322,8 @@ static bool tile11_geom(const ConvArgs& a, int esz) {
   if (a.OH % 16 == 0 && a.OW % 16 == 0) return false;
   if (a.Cout <= 64 || a.Cin < 64) return false;
   const long long wg16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + 15) / 16) * ((a.Cout + 127) / 128);
-  return wg16 <= 1024;
+  static const long long maxwg = getenv("OCTSEG_TILE11_MAXWG") ? atoll(getenv("OCTSEG_TILE11_MAXWG")) : 1024;   // experiments
+  return wg16 <= maxwg;
 }
 
 static Choice choose(const ConvArgs& a, int esz) {
