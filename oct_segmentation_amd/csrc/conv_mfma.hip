@@ -1312,7 +1312,8 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
 struct Choice { Variant v; int dbuf; size_t lds; int resident; int ring3; int ring1; int tile11; };   // ring3: run9r, ring1: run9s (one chunk)
 
 // LOOP_T11's launches: 2-byte 3x3 stride-1 layers with > 64 output channels on maps that are multiples of 11 and not of 16, up to 88 pixels a
-// side, whose 16-pixel tiling is a small grid (<= 1024 workgroups: above that the persistent / ring loops win by their K loop).  `pool_ok` =
+// side, whose 16-pixel tiling is a grid of at most 4608 workgroups (U-Net++/resnet101 16 x 704^2, ms per step of the MFMA kernels alone: off 58.74,
+// <= 1024: 56.38, <= 2304: 56.09, <= 4608: 55.5, no limit 55.68).  `pool_ok` =
 // false: the geometry alone (a pooled destination needs even tiles -- such a launch keeps the 16-pixel tiling but must keep the same weight image)
 static bool tile11_geom(const ConvArgs& a, int esz) {
   static const bool off = getenv("OCTSEG_NO_TILE11") != nullptr;   // A/B switch
@@ -1322,7 +1323,7 @@ static bool tile11_geom(const ConvArgs& a, int esz) {
   if (a.OH % 16 == 0 && a.OW % 16 == 0) return false;
   if (a.Cout <= 64 || a.Cin < 64) return false;
   const long long wg16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + 15) / 16) * ((a.Cout + 127) / 128);
-  static const long long maxwg = getenv("OCTSEG_TILE11_MAXWG") ? atoll(getenv("OCTSEG_TILE11_MAXWG")) : 1024;   // experiments
+  static const long long maxwg = getenv("OCTSEG_TILE11_MAXWG") ? atoll(getenv("OCTSEG_TILE11_MAXWG")) : 4608;   // experiments
   return wg16 <= maxwg;
 }
 
