@@ -1324,7 +1324,11 @@ static bool tile11_geom(const ConvArgs& a, int esz) {
   if (a.Cout <= 64 || a.Cin < 64) return false;
   const long long wg16 = (long long)a.N * ((a.OH + 15) / 16) * ((a.OW + 15) / 16) * ((a.Cout + 127) / 128);
   static const long long maxwg = getenv("OCTSEG_TILE11_MAXWG") ? atoll(getenv("OCTSEG_TILE11_MAXWG")) : 4608;   // experiments
-  return wg16 <= maxwg;
+  // ... and only where the 11-pixel grid gives every CU a workgroup: on a grid that leaves CUs idle a layer takes as long as ONE workgroup, and this
+  // loop restages its window between K chunks with nobody to overlap it (fp16 ensemble, one frame: 147 -> 130 frames/s without this bound)
+  static const long long minwg = getenv("OCTSEG_TILE11_MINWG") ? atoll(getenv("OCTSEG_TILE11_MINWG")) : 256;
+  const long long wg11 = (long long)a.N * (a.OH / 11) * (a.OW / 11) * ((a.Cout + 127) / 128);
+  return wg16 <= maxwg && wg11 >= minwg;
 }
 
 static Choice choose(const ConvArgs& a, int esz) {
