@@ -907,6 +907,51 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
       }
     }
   };
+  // LOOP_T11: the rolled loop with ONE window buffer, the next chunk's window (six passes of a 13 x 13 window) loaded into registers one pass
+  // per tap and stored in place behind the chunk's last barrier -- the loads' latency sits under the chunk's MFMAs instead of in front of the next
+  auto run_t11 = [&](auto np_c) {
+    constexpr int NP = decltype(np_c)::value;   // window passes (host: npass <= NP <= ntaps)
+    int it = 0;
+    int tap2 = 1, chunk2 = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool has_next = chunk + 1 < nchunks;
+      Stager nxt;
+      nxt.setup(a.src, a.nsrc, a.Cin, has_next ? chunk + 1 : chunk, tid, a.src_uniform != 0);
+      nxt.bind_image(n);
+      uint4 av[NP];
+      bool aok[NP];
+      int hy = hy_first, hx = hx_first, hp = p0w;
+#pragma unroll
+      for (int t = 0; t < 9; ++t, ++it) {
+        if (t < NP) {
+          av[t] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[t]);
+          const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+          if (adv) {
+            hp += Stager::PSTEP;
+            hy += dq; hx += dr;
+            if (hx >= RW) { hx -= RW; hy += 1; }
+          }
+        }
+        dmaB(__builtin_amdgcn_readlane(v_tapw, tap2) * nchunks + chunk2, (it + 1) & 1);
+        const int toff = __builtin_amdgcn_readlane(v_toff, t);
+        mma_tap(ldsA, ldsB + (it & 1) * BBYTES, toff);
+        __builtin_amdgcn_sched_barrier(0);
+        // the slab of iteration it + 1 must have landed before anyone passes; the window loads may stay in flight (they are older than
+        // the DMA only in the taps that issued one: wait for everything but keep it simple -- hipcc does not know the DMA)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (++tap2 == 9) { tap2 = 0; chunk2 = min(chunk2 + 1, nchunks - 1); }
+      }
+      if (has_next) {   // every wave is past the last tap's barrier: the window can be replaced
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+          if (u < npass) nxt.write_at(ldsA + (p0w + u * Stager::PSTEP) * PITCH, av[u], aok[u]);
+        __syncthreads();
+      }
+    }
+  };
   // Per-source tap subsets (ConvArgs::taps_per_src): `run` with the tap loop walking the list of the source that owns the chunk -- four taps
   // per 64-channel chunk instead of nine, so the next chunk's window (six passes) is prefetched two passes per tap.  Host-checked: double-
   // buffered window, sources on chunk boundaries, npass <= 2 * taps_per_src.
@@ -1230,6 +1275,8 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     run_masked(std::integral_constant<int, 2>{});
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
     run1p();   // (the rolled loop is not kept as an A/B switch here: with both in one function hipcc moved the by-value ConvArgs to scratch)
+  } else if constexpr (LOOP == LOOP_T11) {   // host-checked: nine taps, one window buffer, six window passes
+    run_t11(std::integral_constant<int, 6>{});
   } else {
     if (dbuf) run(std::integral_constant<int, 1>{}, std::true_type{});
     else run(std::integral_constant<int, 1>{}, std::false_type{});
