@@ -534,7 +534,8 @@ template <int RB> struct ConvCfg { static constexpr int PITCH = RB + 16, KSTEPS 
 //                                 buffer, two workgroups per CU): 3x3 layers on maps that are multiples of 11 but not of 16 -- every 88^2 / 44^2 /
 //                                 22^2 map of a 704^2 frame -- whose 16-pixel tiling ends in a nearly empty round (44^2 at 16 frames: 288 workgroups
 //                                 on 256 CUs; here 512 on 512 slots) or half-empty tiles (22^2: 47 % -> 94.5 %)
-enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4, LOOP_MASKED = 5, LOOP_T11 = 6 };
+//                               7 masked, on 11 x 11 pixel tiles (the tied data gradient over the 44^2 / 22^2 low-resolution maps)
+enum { LOOP_GENERIC = 0, LOOP_RESIDENT = 1, LOOP_1X1 = 2, LOOP_RUN9 = 3, LOOP_RUN9S = 4, LOOP_MASKED = 5, LOOP_T11 = 6, LOOP_MASKED_T11 = 7 };
 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 2) ? 2 : 1)) void conv_mfma_kernel(const ConvArgs a, const int mode) {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
-  constexpr bool T11 = LOOP == LOOP_T11;
+  constexpr bool T11 = LOOP == LOOP_T11 || LOOP == LOOP_MASKED_T11;
   const TilePos tp = map_tile<TH, BN, T11>(a);
   const int n = tp.n, y0 = tp.y0, x0 = tp.x0, nt_idx = tp.nt_idx;
 
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     cur.setup(a.src, a.nsrc, a.Cin, 0, tid);
     if (resident) {
       for (int t = 0; t < a.ntaps; ++t) dmaB(a.tap_w[t] * nchunks, t);
-    } else if constexpr (LOOP == LOOP_MASKED) {
+    } else if constexpr (LOOP == LOOP_MASKED || LOOP == LOOP_MASKED_T11) {
       dmaB(a.tap_w[a.src_taps[0] & 15] * nchunks, 0);   // first tap of the first source's list
     } else {
       dmaB(a.tap_w[0] * nchunks, 0);
@@ -1236,6 +1237,68 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail slabs
     __syncthreads();
   };
+  // Per-source tap subsets on the 4-wave tile with ONE window buffer (two workgroups per CU): four taps per 64-channel chunk, the next chunk's
+  // window (six passes of a 10 x 18 or 13 x 13 window) loaded into registers over those taps (2 + 2 + 1 + 1) and stored in place behind the
+  // chunk's last barrier.  Host-checked: taps_per_src == 4, npass <= 6.
+  auto run_masked_rp = [&]() {
+    constexpr int NP = 6, TPS = 4;
+    auto list_of = [&](int chunk) -> int {
+      int l = a.src_taps[0];
+#pragma unroll
+      for (int i = 1; i < MAX_SRC; ++i)
+        if (i < a.nsrc && chunk * KC >= a.src[i].c0) l = a.src_taps[i];
+      return l;
+    };
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool has_next = chunk + 1 < nchunks;
+      const int cnext = has_next ? chunk + 1 : chunk;
+      Stager nxt;
+      nxt.setup(a.src, a.nsrc, a.Cin, cnext, tid, a.src_uniform != 0);
+      nxt.bind_image(n);
+      const int lst = list_of(chunk), lst_n = list_of(cnext);
+      uint4 av[NP];
+      bool aok[NP];
+      int hy = hy_first, hx = hx_first, hp = p0w;
+      auto load_pass = [&](auto uc) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        av[U] = nxt.load_at(hy, hx, hp < npix, gy0, gx0, smul, IHl, IWl, aok[U]);
+        const bool adv = hp + Stager::PSTEP < npass * Stager::PSTEP;
+        if (adv) {
+          hp += Stager::PSTEP;
+          hy += dq; hx += dr;
+          if (hx >= RW) { hx -= RW; hy += 1; }
+        }
+      };
+      auto tap = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        const int t = (lst >> (4 * K)) & 15;
+        if constexpr (K == 0) { load_pass(std::integral_constant<int, 0>{}); load_pass(std::integral_constant<int, 1>{}); }
+        if constexpr (K == 1) { load_pass(std::integral_constant<int, 2>{}); load_pass(std::integral_constant<int, 3>{}); }
+        if constexpr (K == 2) load_pass(std::integral_constant<int, 4>{});
+        if constexpr (K == 3) load_pass(std::integral_constant<int, 5>{});
+        const bool same = K + 1 < TPS;
+        const int tn = same ? (lst >> (4 * (K + 1))) & 15 : lst_n & 15;
+        dmaB(__builtin_amdgcn_readlane(v_tapw, tn) * nchunks + (same ? chunk : cnext), (it + 1) & 1);
+        const int toff = __builtin_amdgcn_readlane(v_toff, t);
+        mma_tap(ldsA, ldsB + (it & 1) * BBYTES, toff);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ++it;
+      };
+      tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
+      tap(std::integral_constant<int, 2>{}); tap(std::integral_constant<int, 3>{});
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+          if (u < npass) nxt.write_at(ldsA + (p0w + u * Stager::PSTEP) * PITCH, av[u], aok[u]);
+        __syncthreads();
+      }
+    }
+  };
   if constexpr (LOOP == LOOP_RESIDENT) {
     for (int t = 0; t < ntaps; ++t) mma_tap(ldsA, ldsB + t * BBYTES, __builtin_amdgcn_readlane(v_toff, t));
     __syncthreads();   // the epilogue reuses the LDS
@@ -1271,8 +1334,11 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
     }
   } else if constexpr (LOOP == LOOP_RUN9) {   // host-checked: dbuf, 9 taps, npass <= 8, slab pieces divide over the waves
     if constexpr (NDMA % NWAVES == 0 && (RB == 128 || (RB == 64 && NT == 4))) run9r();
-  } else if constexpr (LOOP == LOOP_MASKED) {   // host-checked: dbuf, per-source tap lists, npass <= 2 * taps_per_src
-    run_masked(std::integral_constant<int, 2>{});
+  } else if constexpr (LOOP == LOOP_MASKED_T11) {   // host-checked: per-source lists of four taps, one window buffer, six passes
+    run_masked_rp();
+  } else if constexpr (LOOP == LOOP_MASKED) {   // host-checked: per-source tap lists; dbuf (npass <= 2 * taps_per_src), or one buffer on the 4-wave tile
+    if constexpr (WM == 2) { if (dbuf) run_masked(std::integral_constant<int, 2>{}); else run_masked_rp(); }
+    else run_masked(std::integral_constant<int, 2>{});
   } else if constexpr (LOOP == LOOP_1X1) {    // host-checked: dbuf, one tap (at most four window passes)
     run1p();   // (the rolled loop is not kept as an A/B switch here: with both in one function hipcc moved the by-value ConvArgs to scratch)
   } else if constexpr (LOOP == LOOP_T11) {   // host-checked: nine taps, one window buffer, six window passes
@@ -1320,7 +1386,7 @@ size_t variant_lds(const ConvArgs& a, const Variant& v, int esz, int dbuf, int* 
 template <typename T, int NT, int WN, int WM, int RB, int LOOP>
 hipError_t launch_loop(const ConvArgs& a, int mode, size_t lds, hipStream_t st) {
   constexpr int BN = NT * 32 * WN, TH = 2 * wave_mt(NT, RB) * WM;
-  const int mtiles = LOOP == LOOP_T11 ? a.N * (a.OH / 11) * (a.OW / 11) : a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
+  const int mtiles = (LOOP == LOOP_T11 || LOOP == LOOP_MASKED_T11) ? a.N * (a.OH / 11) * (a.OW / 11) : a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
   dim3 grid(mtiles, (a.Cout + BN - 1) / BN);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1346,6 +1412,9 @@ hipError_t launch_variant(const ConvArgs& a, int mode, int loop, size_t lds, hip
       else return hipErrorInvalidValue;
     case LOOP_MASKED:
       if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_MASKED>(a, mode, lds, st);
+      else return hipErrorInvalidValue;
+    case LOOP_MASKED_T11:
+      if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2 && WN == 2 && WM == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_MASKED_T11>(a, mode, lds, st);
       else return hipErrorInvalidValue;
     case LOOP_T11:
       if constexpr (RB == 128 && sizeof(T) == 2 && NT == 2 && WN == 2 && WM == 2) return launch_loop<T, NT, WN, WM, RB, LOOP_T11>(a, mode, lds, st);
@@ -1393,7 +1462,20 @@ static Choice choose(const ConvArgs& a, int esz) {
       return c;
     }
   }
-  if (a.taps_per_src > 0) {   // masked loop: the 128-channel N tile, 64-channel chunks, double-buffered window (conv_masked_eligible checked the rest)
+  if (a.taps_per_src > 0) {   // masked loop: the 128-channel N tile, 64-channel chunks (conv_masked_eligible checked the rest)
+    // four taps per source: the 4-wave tile with one window buffer, two workgroups per CU -- on 11 x 11 pixels where the map is a multiple of 11
+    // and not of 16 (the 44^2 / 22^2 low-resolution maps of the deep decoder blocks), else 8 x 16 (OCTSEG_MASKED_DBUF: the double-buffered 16 x 16 form)
+    static const bool force_dbuf = getenv("OCTSEG_MASKED_DBUF") != nullptr;   // A/B switch
+    if (!force_dbuf && a.taps_per_src == 4 && esz == 2 && a.ntaps == 9 && a.span_x == 3 && a.span_y == 3) {
+      c.v = Variant{2, 2, 2, 128}; c.dbuf = 0; c.resident = 0;
+      bool pool = false;
+      for (int i = 0; i < a.ndst; ++i) pool = pool || a.dst[i].pool != 0;
+      c.tile11 = (!pool && a.OH % 11 == 0 && a.OW % 11 == 0 && !(a.OH % 16 == 0 && a.OW % 16 == 0) && a.OH <= 88 && a.OW <= 88) ? 1 : 0;
+      const size_t main_loop = (size_t)6 * 32 * 144 + 2 * (size_t)128 * 128;
+      const size_t epi = (size_t)128 * (128 * esz + 16) + (size_t)2 * 128 * 2 * sizeof(float);
+      c.lds = main_loop > epi ? main_loop : epi;
+      return c;
+    }
     for (int wm = 4; wm >= 2; wm -= 2) {
       const Variant v{2, 2, wm, 128};
       int npass = 0;
@@ -1544,7 +1626,7 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
     static const bool no_usrc = getenv("OCTSEG_NO_UNIFORM_SRC") != nullptr;   // A/B switch
     if (no_usrc) a.src_uniform = 0;
   }
-  const int loop = c.tile11 ? LOOP_T11 : a.taps_per_src > 0 ? LOOP_MASKED
+  const int loop = a.taps_per_src > 0 ? (c.tile11 ? LOOP_MASKED_T11 : LOOP_MASKED) : c.tile11 ? LOOP_T11
                    : c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
