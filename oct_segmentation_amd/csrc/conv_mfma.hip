@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((WM * WN == 4 && wave_mt(NT, RB) == 
   auto run_masked_rp = [&]() {
     constexpr int NP = 6, TPS = 4;
     auto list_of = [&](int chunk) -> int {
+      if (a.taps_per_src == 0) return 0x3210;   // a plain four-tap launch (one ConvTranspose2d parity): every chunk meets taps 0 .. 3
       int l = a.src_taps[0];
 #pragma unroll
       for (int i = 1; i < MAX_SRC; ++i)
@@ -1462,6 +1463,19 @@ static Choice choose(const ConvArgs& a, int esz) {
       return c;
     }
   }
+  {
+    // plain four-tap stride-1 launches (a ConvTranspose2d forward parity: 2 x 2 taps, output stride 2) with > 64 output channels: the masked loop's
+    // 4-wave tile with one window buffer and register prefetch (every chunk meets all four taps); OCTSEG_NO_RP4: the rolled loop (A/B switch)
+    static const bool no_rp4 = getenv("OCTSEG_NO_RP4") != nullptr;
+    if (!no_rp4 && esz == 2 && a.taps_per_src == 0 && a.ntaps == 4 && a.span_x == 2 && a.span_y == 2 && a.istride == 1 &&
+        a.out_mode != OUT_HEAD_NCHW && a.Cout > 64 && a.Cin >= 64) {
+      c.v = Variant{2, 2, 2, 128}; c.dbuf = 0; c.resident = 0; c.tile11 = 3;   // (3: the masked loop without per-source lists)
+      const size_t main_loop = (size_t)6 * 32 * 144 + 2 * (size_t)128 * 128;
+      const size_t epi = (size_t)128 * (128 * esz + 16) + (size_t)2 * 128 * 2 * sizeof(float);
+      c.lds = main_loop > epi ? main_loop : epi;
+      return c;
+    }
+  }
   if (a.taps_per_src > 0) {   // masked loop: the 128-channel N tile, 64-channel chunks (conv_masked_eligible checked the rest)
     // four taps per source: the 4-wave tile with one window buffer, two workgroups per CU -- on 11 x 11 pixels where the map is a multiple of 11
     // and not of 16 (the 44^2 / 22^2 low-resolution maps of the deep decoder blocks), else 8 x 16 (OCTSEG_MASKED_DBUF: the double-buffered 16 x 16 form)
@@ -1626,7 +1640,7 @@ hipError_t dispatch(const ConvArgs& a_in, hipStream_t st) {
     static const bool no_usrc = getenv("OCTSEG_NO_UNIFORM_SRC") != nullptr;   // A/B switch
     if (no_usrc) a.src_uniform = 0;
   }
-  const int loop = a.taps_per_src > 0 ? (c.tile11 ? LOOP_MASKED_T11 : LOOP_MASKED) : c.tile11 ? LOOP_T11
+  const int loop = a.taps_per_src > 0 ? (c.tile11 ? LOOP_MASKED_T11 : LOOP_MASKED) : c.tile11 == 3 ? LOOP_MASKED : c.tile11 ? LOOP_T11
                    : c.resident ? LOOP_RESIDENT : (c.ring3 ? LOOP_RUN9 : (c.ring1 ? LOOP_RUN9S : ((a.ntaps == 1 && c.dbuf) ? LOOP_1X1 : LOOP_GENERIC)));
 #define OCTSEG_CASE(NT_, WN_, WM_, RB_)                                             \
   if (v.NT == NT_ && v.WN == WN_ && v.WM == WM_ && v.RB == RB_)                     \
@@ -1663,7 +1677,7 @@ ConvPackInfo conv_pack_info(const ConvArgs& a, int dtype) {
 
 int conv_num_mtiles(const ConvArgs& a, int dtype) {
   const Choice c = choose(a, (int)dtype_size(dtype));
-  if (c.tile11) return a.N * (a.OH / 11) * (a.OW / 11);
+  if (c.tile11 == 1) return a.N * (a.OH / 11) * (a.OW / 11);
   const int TH = 2 * wave_mt(c.v.NT, c.v.RB) * c.v.WM;
   return a.N * ((a.OH + TH - 1) / TH) * ((a.OW + TW - 1) / TW);
 }
