@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# conv_mfma.hip takes its 11 x 11 pixel tiles (3x3 layers on maps that are multiples of 11 and not of 16) only on grids that give every CU a
+# workgroup -- a speed rule (OCTSEG_TILE11_MINWG, default 256, read once per process).  The parity tests run two or three frames: without this
+# they would compare the 16-pixel tilings only.  Set before the library is first used; the 704^2 batch-16 tests cover the default routing.
+os.environ.setdefault('OCTSEG_TILE11_MINWG', '1')
+
 
 def _usable_cores():
     """CPU threads this process may really use (bench.py host_cores): the affinity mask, cut to the cgroup quota; a one-GPU job on the
