@@ -99,6 +99,8 @@ struct WgradArgs {
   float* dW;        // [wtaps][Cout][Cin] fp32, accumulated with atomics
   int ksplit;       // number of pixel-tile groups (grid.z)
   int co_fast;      // set by the launcher: co tiles fastest in the XCD-local workgroup order (speed only)
+  int wg_target;    // 0: the launcher's default split-K width (one workgroup per CU); > 0: at most this many workgroups -- the plan asks for a
+                    // narrower launch when the weight gradient runs on the side stream BESIDE the chain's kernels (plan.cpp side_wgs)
   unsigned long long* stamp;  // diagnostic builds (-DOCTSEG_STAMP) only
 };
 

@@ -1481,6 +1481,16 @@ static int pack_all_weights(Exec& E, bool fold) {
 
 static const void* fwd_weight(const Exec& E, const ConvLayer& L) { return E.ws + L.wimg_fwd_off; }
 
+// Split-K width of the multi-tap weight gradients when they run on the side stream beside the chain's kernels.  A weight gradient that fills
+// all 256 CUs with one long-running workgroup each (110-150 KB of LDS, 380 registers) leaves the data gradient and the BatchNorm sweeps of the
+// chain nothing to start on until its workgroups retire; on 144-160 CUs it takes 30 % longer by itself (24.5 against 18.9 ms per step at 160, alone)
+// and the step gets shorter: 65.1 -> 63.0 ms at 144 workgroups (ABAB on one box; 112: 67.8, 128: 63.5, 136: 63.0, 152: 63.3, 160: 63.4-63.7, 176: 63.7).  On the caller's own stream (one-stream
+// mode, the kernels-alone pass of bench.py) nothing runs beside it and it keeps the full width.  OCTSEG_WGRAD_SIDE_WGS=n (A/B; 256 = full width).
+static int side_wgs() {
+  static const int v = getenv("OCTSEG_WGRAD_SIDE_WGS") ? atoi(getenv("OCTSEG_WGRAD_SIDE_WGS")) : 144;
+  return v;
+}
+
 static Geom tie_geom_up(const ConvLayer& L) { return Geom{4, 4, 2, 1, true, L.N, L.IH / 2, L.IW / 2, L.tie_Ca, L.OH, L.OW, L.Cout}; }
 static Geom tie_geom_skip(const ConvLayer& L) { return Geom{3, 3, 1, 1, false, L.N, L.IH, L.IW, L.tie_Cs, L.OH, L.OW, L.Cout}; }
 
@@ -2020,6 +2030,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
       for (auto& a : lw) {
         a.nsrc = 1; a.src[0] = src[0]; a.src[0].up = 0; a.src[0].c0 = 0;
         a.dy = dy; a.dyC = dyC; a.dW = dK4; a.stamp = nullptr;
+        a.wg_target = ws_ != E.st ? side_wgs() : 0;
       }
       if (wgrad_convt16_eligible(lw[0], P->dtype)) {   // all four parities from one staged window (wgrad_convt.hip)
         ProfScope ps(2, 2.0 * macs * Ca / L.Cin, ws_, L.name);
@@ -2037,6 +2048,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
         a.nsrc = ns - 1;
         for (int i = 1; i < ns; ++i) { a.src[i - 1] = src[i]; a.src[i - 1].c0 -= Ca; }
         a.dy = dy; a.dyC = dyC; a.dW = dW3s; a.stamp = nullptr;
+        a.wg_target = ws_ != E.st ? side_wgs() : 0;
         ProfScope ps(2, 2.0 * macs * Cs / L.Cin, ws_, L.name);
         HIPCHK(launch_wgrad(P->dtype, a, ws_));
       }
@@ -2049,6 +2061,7 @@ static int conv_backward(Exec& E, const ConvLayer& L, const void* dy, int dyC) {
         a.dy = dy; a.dyC = dyC;
         a.dW = E.grads + P->params[L.w].off;
         a.stamp = nullptr;
+        a.wg_target = ws_ != E.st ? side_wgs() : 0;
       }
       if (L.transposed && lw.size() == 4 && wgrad_convt16_eligible(lw[0], P->dtype)) {   // ConvTranspose2d: the four parities in one launch
         ProfScope ps(2, 2.0 * layer_macs(L), ws_, L.name);

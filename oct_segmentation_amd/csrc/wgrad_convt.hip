@@ -296,7 +296,7 @@ hipError_t launch_wgrad_convt16(int dtype, const WgradArgs& a0, hipStream_t st) 
   const int ntiles = a.N * ((a.OW + TW - 1) / TW) * ((a.OH + CT_TH - 1) / CT_TH);
   const int gx = (a.Cin + 63) / 64, gy = (a.Cout + 63) / 64;
   static const int wg_env = getenv("OCTSEG_WGRAD_WGS") ? atoi(getenv("OCTSEG_WGRAD_WGS")) : 0;   // experiments
-  int ks = (wg_env > 0 ? wg_env : 256) / (gx * gy);
+  int ks = (wg_env > 0 ? wg_env : (a.wg_target > 0 ? a.wg_target : 256)) / (gx * gy);
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
   if (deterministic_mode()) ks = 1;   // one writer per dW element: a fixed summation order

@@ -514,7 +514,7 @@ static hipError_t launch_wgrad_t(const WgradArgs& a0, int dtype, hipStream_t st)
   // pixels each) halve it: encoder 3x3 wgrad 3.89 -> 2.98 ms per step, decoder 14.7 -> 14.4.  1x1 layers flush 16 KiB tiles and want
   // the occupancy: 512 there (256 measured 2.7 -> 3.7 ms).
   static const int wg_env = getenv("OCTSEG_WGRAD_WGS") ? atoi(getenv("OCTSEG_WGRAD_WGS")) : 0;   // experiments
-  const int wg_target = wg_env > 0 ? wg_env : (NTAPS == 1 ? 512 : 256);
+  const int wg_target = wg_env > 0 ? wg_env : (NTAPS == 1 ? 512 : (a.wg_target > 0 ? a.wg_target : 256));
   int ks = wg_target / (gx * gy);
   if (ks > ntiles) ks = ntiles;
   if (ks < 1) ks = 1;
